@@ -1,0 +1,118 @@
+/* pt_hip.h — C ABI of libpt_hip.so, the MI355X (gfx950) path-tracing backend.
+ *
+ * This is the inner boundary of the drop-in: the thin C host (pathtracer_amd/csrc/renderer.c,
+ * which keeps the reference's 15-function renderer.h API) calls these entry points
+ * where the reference's host called OpenCL.  Plain C: pointers, sizes, ints.  Every
+ * function returns 0 on success or a negative PT_E_* code; pt_last_error() gives the text.
+ *
+ * Each entry point cites the reference interface it replaces (paths relative to the
+ * reference checkout).
+ */
+#ifndef PT_HIP_H
+#define PT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PT_OK            0
+#define PT_E_INVALID    -1   /* bad argument (NULL, non-positive size, partition out of range) */
+#define PT_E_DEVICE     -2   /* HIP runtime error (no device, launch failure, ...) */
+#define PT_E_NOMEM      -3   /* device or host allocation failed */
+#define PT_E_STATE      -4   /* call order: no scene / no image set */
+
+/* Interchange sphere record, 12 floats (48 B), used by every layer of this repo:
+ *   cx cy cz radius | type colr colg colb | tint fuzzyness refIdx pad
+ * `type` holds the reference's material code as a float: 0 light, 1 lambertian,
+ * 2 metal, 3 dielectric (src/c/renderer.c:119-133).  It is the flattened form of the
+ * reference's 80-byte `Sphere` (src/c/renderer.h:32-44); the backend re-lays it out as
+ * structure-of-arrays device tables. */
+#define PT_SPHERE_FLOATS 12
+
+typedef struct pt_ctx pt_ctx;
+
+/* Arguments of one render call = the reference's per-sample launch loop
+ * (src/c/renderer.c:159-179: kernel args 1..3, 5, 6) folded into ONE launch. */
+typedef struct pt_render_args {
+	int width, height;        /* ImageInfo.size          (src/c/renderer.h:22-25) */
+	int max_depth;            /* ImageInfo.maxRayDepth */
+	float background[3];      /* SceneInfo.color         (src/c/renderer.h:27-30) */
+	float cam_pos[3];         /* Camera                  (src/c/renderer.h:46-53) */
+	float cam_rot[3];
+	float sensor_width, focal_length, aperture, exposure;
+	const uint64_t *seeds;    /* HOST array, n_frames entries: seeds[k] is the `seed` kernel arg of
+	                             sample first_frame+k (src/c/renderer.c:172,176) */
+	int first_frame;          /* `frame` kernel arg of the first sample (src/c/renderer.c:175);
+	                             0 overwrites the accumulator, >0 continues its running mean */
+	int n_frames;             /* samples to run in this call */
+	/* Row-band partition for multi-GPU (no reference counterpart): image rows are
+	 * cut into bands of band_rows rows, band b is rendered by rank b % world.  Work-item ids stay
+	 * global, so every pixel is bit-identical to the single-GPU image.  Pixels of other ranks are
+	 * not touched.  rank=0, world=1 renders everything. */
+	int rank, world, band_rows;
+	void *d_image;            /* device pointer to width*height float4 accumulators (the reference's
+	                             `global float3 *image`, 16 B per pixel, src/cl/main.cl:4), or NULL to
+	                             use the context's own buffer (pt_image_alloc) */
+	void *stream;             /* hipStream_t to launch on, or NULL for the context's stream */
+	uint64_t *bounce_count;   /* optional HOST out: bounce-loop iterations executed (src/cl/ray.cl:96)
+	                             over all samples of this call — the B of SURVEY.md §8d.  Forces a
+	                             synchronisation.  NULL: not counted. */
+	int async;                /* 0: return after the kernel has finished (the reference's clFinish,
+	                             src/c/renderer.c:251).  1: return after enqueue. */
+} pt_render_args;
+
+/* Text of the last error on this thread ("" if none). */
+const char *pt_last_error(void);
+
+/* Number of visible HIP devices.  Replaces clGetPlatformIDs/clGetDeviceIDs (src/c/renderer.c:68,72). */
+int pt_device_count(int *count);
+
+/* Create a backend context on `device`: selects the device, creates its stream.  Replaces
+ * clCreateContext / clCreateCommandQueueWithProperties / clCreateProgramWithSource /
+ * clBuildProgram / clCreateKernel (src/c/renderer.c:75-94) — the kernels are compiled ahead
+ * of time into this library, so there is no run-time build step that can fail. */
+int pt_ctx_create(int device, pt_ctx **out);
+
+/* Destroy the context and free its device memory.  Replaces clRelease* (src/c/renderer.c:295-303). */
+int pt_ctx_destroy(pt_ctx *ctx);
+
+/* (Re)allocate the context's own accumulator, width*height float4, zero-filled.
+ * Replaces clCreateBuffer(imageBuff) in set_image_properties (src/c/renderer.c:103). */
+int pt_image_alloc(pt_ctx *ctx, int width, int height);
+
+/* Upload the scene: n interchange records (HOST) -> SoA device tables.  n may be 0.
+ * Replaces clCreateBuffer(sphereBuff) + clEnqueueWriteBuffer (src/c/renderer.c:155-156). */
+int pt_scene_upload(pt_ctx *ctx, const float *spheres, int n);
+
+/* Render args->n_frames samples of every pixel this rank owns.  Replaces the sample loop
+ * clSetKernelArg ×7 + clEnqueueNDRangeKernel + clFinish (src/c/renderer.c:159-179,251). */
+int pt_render(pt_ctx *ctx, const pt_render_args *args);
+
+/* Block until everything enqueued on the context's stream has finished (clFinish, src/c/renderer.c:273). */
+int pt_sync(pt_ctx *ctx);
+
+/* Copy the context's accumulator to HOST memory, width*height*4 floats.
+ * Replaces clEnqueueReadBuffer (src/c/renderer.c:271). */
+int pt_image_read(pt_ctx *ctx, float *host_rgba);
+
+/* Device epilogue + copy: gamma (sqrt), clamp to [0,1], (int)(x*255) truncation -> width*height*3
+ * bytes RGB, row-major, in HOST memory.  Replaces gamma_correct_data + convert_to_image
+ * (src/c/renderer.c:50-56,17-39) and shrinks the read-back from 16 to 3 bytes per pixel.
+ * d_image: accumulator to convert (NULL: the context's own, sized by pt_image_alloc). */
+int pt_image_read_u8(pt_ctx *ctx, const void *d_image, int width, int height, unsigned char *host_rgb);
+
+/* Self-test hooks used by tests/ to pin the device arithmetic against the oracle, one function
+ * of the reference kernel at a time.  All pointers are HOST; n items each.
+ *   op 0: init_rng_2(a[i], b[i])                 -> out_u64[i]                (src/cl/rng.cl:7-9)
+ *   op 1: state a[i]: rand_float                  -> out_u64[i]=state, out_f[i] (src/cl/rng.cl:11-14)
+ *   op 2: state a[i]: random_unit_vector          -> out_u64[i]=state, out_f[3i..] (src/cl/rng.cl:20-34)
+ *   op 3: in_f[2i]=x, in_f[2i+1]=y: x/y, sqrt(x), reflectance(x,y), pow5(x) -> out_f[4i..] */
+int pt_selftest(pt_ctx *ctx, int op, const uint64_t *a, const uint64_t *b, const float *in_f,
+                int n, uint64_t *out_u64, float *out_f);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

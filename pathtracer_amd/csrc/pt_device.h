@@ -1,0 +1,97 @@
+// pt_device.h — device-side arithmetic of the path tracer, shared by every kernel variant.
+//
+// Hand-written for gfx950.  Float semantics are the contract: strict IEEE-754 binary32
+// in the reference's operation order, no FMA contraction (the build passes
+// -ffp-contract=off), correctly rounded divide and sqrt
+// (-fhip-fp32-correctly-rounded-divide-sqrt), denormals kept.  Under those rules every
+// function below is bit-identical to the CPU oracle (oracle/pt_oracle.c), which is
+// itself bit-identical to the strict x86 build of the reference kernel.  Citations are
+// to the reference (src/cl/*.cl) for what each function must compute.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+struct f3 { float x, y, z; };
+
+#define PT_DEV __device__ __forceinline__
+
+PT_DEV f3 mk3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
+PT_DEV f3 add3(f3 a, f3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+PT_DEV f3 sub3(f3 a, f3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+PT_DEV f3 mul3(f3 a, f3 b) { return mk3(a.x * b.x, a.y * b.y, a.z * b.z); }
+PT_DEV f3 scl3(f3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
+// OpenCL dot/length/normalize as pinned in oracle/ref_shim.cpp
+PT_DEV float dot3(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+PT_DEV float len3(f3 a) { return sqrtf(dot3(a, a)); }
+PT_DEV f3 norm3(f3 a) { float inv = 1.0f / len3(a); return scl3(a, inv); }
+
+constexpr uint32_t PT_M31 = 2147483647u;   // MINSTD modulus 2^31 - 1 (src/cl/rng.cl:12)
+
+// x mod (2^31 - 1) for any 64-bit x, by Mersenne folding (2^31 == 1 mod M): no 64-bit divide.
+PT_DEV uint32_t mod_m31(uint64_t x) {
+	// three 31-bit limbs: bits 0-30, 31-61, 62-63
+	uint32_t s = (uint32_t)(x & PT_M31) + (uint32_t)((x >> 31) & PT_M31);   // < 2^32 - 1, no wrap
+	uint32_t t = (s & PT_M31) + (s >> 31) + (uint32_t)(x >> 62);            // <= M + 1 + 3
+	uint32_t u = t - PT_M31;                                                // wraps high when t < M
+	return u < t ? u : t;                                                   // t >= M ? t - M : t
+}
+
+// src/cl/rng.cl:7-9 — (16807*a*b) % M * (16807*a*b) % M, left-assoc, wrapping at 2^64.
+// `xb` = 16807*b mod 2^64 is the same for every work-item of a sample; the host folds it once.
+PT_DEV uint32_t init_rng_2(uint32_t id, uint64_t xb) {
+	uint64_t x = (uint64_t)id * xb;
+	uint64_t y = (uint64_t)mod_m31(x) * x;
+	return mod_m31(y);
+}
+
+// src/cl/rng.cl:11-14 — state = 16807*state % M; return (float)(state / 2147483647.0).
+// The state stays below 2^31, so the product stays below 2^46 and one fold is enough.
+// The f64 divide is replaced by a multiply with RN(1/M): tests/test_rng_exhaustive.py proves
+// (on the CPU, all 2^31 states) that the narrowed float is identical.
+PT_DEV float rand_float(uint32_t &state) {
+	uint64_t p = (uint64_t)state * 16807u;
+	uint32_t t = (uint32_t)(p & PT_M31) + (uint32_t)(p >> 31);
+	uint32_t u = t - PT_M31;
+	state = u < t ? u : t;
+	return (float)((double)state * (1.0 / 2147483647.0));
+}
+
+// src/cl/rng.cl:16-18 with a=-1, b=1:  -1 + r*(1 - -1)
+PT_DEV float rand_pm1(uint32_t &state) { return -1.0f + rand_float(state) * 2.0f; }
+
+// src/cl/rng.cl:20-34 — theta draw first; y >= 0 always (kept: not a uniform sphere sample).
+PT_DEV f3 random_unit_vector(uint32_t &state) {
+	float cosTheta = rand_pm1(state);
+	float cosPhi = rand_pm1(state);
+	float sinTheta = sqrtf(1.0f - cosTheta * cosTheta);
+	float sinPhi = sqrtf(1.0f - cosPhi * cosPhi);
+	return mk3(sinTheta * cosPhi, sinTheta * sinPhi, cosTheta);
+}
+
+// src/cl/ray.cl:54-56 — in - (normal*2)*dot(in,normal)
+PT_DEV f3 reflection_dir(f3 in, f3 n) { return sub3(in, scl3(scl3(n, 2.0f), dot3(in, n))); }
+
+// pow(x,5) of oracle/ref_shim.cpp = (float)pow((double)x,5.0): x^5 in f64 (x^2 exact, two
+// roundings after) narrowed to f32 — identical except on a ~2^-29 double-rounding sliver.
+PT_DEV float pow5(float x) {
+	double d = (double)x;
+	double d2 = d * d;
+	double d4 = d2 * d2;
+	return (float)(d4 * d);
+}
+
+// src/cl/ray.cl:58-62 — Schlick
+PT_DEV float reflectance(float cosTheta, float rel) {
+	float r = (1.0f - rel) / (1.0f + rel);
+	r = r * r;
+	return r + (1.0f - r) * pow5(1.0f - cosTheta);
+}
+
+// src/cl/ray.cl:64-69
+PT_DEV f3 refraction_dir(f3 in, f3 n, float rel) {
+	float cosTheta = fminf(dot3(scl3(in, -1.0f), n), 1.0f);
+	f3 perp = scl3(add3(in, scl3(n, cosTheta)), rel);
+	float lp = len3(perp);
+	f3 par = scl3(n, -sqrtf(fabsf(1.0f - lp * lp)));
+	return add3(par, perp);
+}

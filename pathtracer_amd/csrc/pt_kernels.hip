@@ -1,0 +1,461 @@
+// pt_kernels.hip — gfx950 path-tracing kernels and the C ABI of libpt_hip.so (include/pt_hip.h).
+//
+// Replaces the reference's OpenCL kernel `main` (src/cl/main.cl:4-30, src/cl/ray.cl,
+// src/cl/rng.cl) and the device side of its host loop (src/c/renderer.c:153-262).
+// Not a translation: one launch renders ALL samples of a pixel with the accumulator in
+// registers (the reference re-launches per sample and read-modify-writes 32 B per sample
+// per pixel), the scene is structure-of-arrays (geometry table read through wave-uniform
+// scalar loads, material table gathered only for the winning sphere), the RNG is 32-bit
+// with Mersenne folding instead of 64-bit remainders, and per-launch uniform
+// trigonometry is folded on the host.
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fno-fast-math
+//        -fhip-fp32-correctly-rounded-divide-sqrt  (see __graft_entry__.build()).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "pt_device.h"
+#include "pt_hip.h"
+
+// ---------------------------------------------------------------------------------------
+// Kernel parameters (by value: land in SGPRs — the reference passes its three structs by
+// value too, src/c/renderer.c:160-162)
+// ---------------------------------------------------------------------------------------
+struct KParams {
+	int W, H, maxDepth, n;
+	float bgx, bgy, bgz;
+	float px, py, pz;                   // Camera.pos
+	float cosRx, sinRx, cosRy, sinRy;   // cosf/sinf of Camera.rot.x / .y, folded on the host (rot.z is dead, src/cl/ray.cl:42-43)
+	float sensorWidth, focalLength, aperture, exposure;
+	int firstFrame, nFrames;
+	int rank, world, bandRows;          // row-band partition (pt_hip.h)
+	int localPixels;                    // pixels of this rank = threads that do work
+};
+
+// Device scene tables (SoA).  geom[i] = {cx, cy, cz, r*r}; matA[i] = {colr, colg, colb, type bits};
+// matB[i] = {tint, fuzz, refIdx, 0}.
+struct SceneTables {
+	const float4 *geom;
+	const float4 *matA;
+	const float4 *matB;
+};
+
+// Thread -> global work-item id under the row-band partition.  Returns -1 past the end.
+PT_DEV int pixel_id(const KParams &p, int t) {
+	if(t >= p.localPixels) return -1;
+	int lrow = t / p.W, col = t - lrow * p.W;
+	int lband = lrow / p.bandRows, rin = lrow - lband * p.bandRows;
+	int row = (lband * p.world + p.rank) * p.bandRows + rin;
+	return row < p.H ? row * p.W + col : -1;
+}
+
+// src/cl/main.cl:8-17 — the part of the camera ray that does not depend on the sample.
+PT_DEV f3 camera_origin(const KParams &p, int id) {
+	int row = id / p.W, column = id - row * p.W;
+	float aspect = (float)p.W / (float)p.H;
+	float xOff = 2.0f * (float)(column - p.W / 2) / (float)p.W * p.sensorWidth;
+	float yOff = 2.0f * (float)(row - p.H / 2) / (float)p.H * p.sensorWidth / aspect;
+	f3 v = mk3(-xOff, yOff, p.focalLength);
+	// rotate_vector as it nets out (src/cl/ray.cl:39-52)
+	f3 r = mk3(v.x * p.cosRy + v.z * p.sinRy, v.y * p.cosRx - v.z * p.sinRx, v.y * p.sinRx + v.z * p.cosRx);
+	return add3(mk3(p.px, p.py, p.pz), r);
+}
+
+// ---------------------------------------------------------------------------------------
+// Kernel v1: one thread per pixel, all samples in-kernel, lock-step sample loop.
+// ---------------------------------------------------------------------------------------
+template <bool COUNT>
+__global__ __launch_bounds__(256) void pt_render_kernel(float4 *__restrict__ image, const KParams p, const SceneTables sc,
+                                                         const uint64_t *__restrict__ seedmul,
+                                                         unsigned long long *__restrict__ bounceCounter) {
+	const int id = pixel_id(p, (int)(blockIdx.x * blockDim.x + threadIdx.x));
+	unsigned int myBounces = 0;
+	if(id >= 0) {
+		const f3 pos = mk3(p.px, p.py, p.pz);
+		const f3 origin = camera_origin(p, id);
+		f3 acc = mk3(0.0f, 0.0f, 0.0f);
+		if(p.firstFrame > 0) {
+			float4 v = image[id];
+			acc = mk3(v.x, v.y, v.z);
+		}
+		for(int k = 0; k < p.nFrames; k++) {
+			uint32_t rng = init_rng_2((uint32_t)id, seedmul[k]);                       // main.cl:6
+			f3 target = add3(pos, scl3(random_unit_vector(rng), p.aperture));            // main.cl:19
+			f3 d = norm3(sub3(target, origin));                                          // main.cl:21
+			f3 o = pos;                                                                  // main.cl:23
+			f3 color = mk3(0.0f, 0.0f, 0.0f), mask = mk3(1.0f, 1.0f, 1.0f);              // ray.cl:92-93
+			for(int j = 0; j < p.maxDepth; j++) {                                        // ray.cl:96
+				if(COUNT) myBounces++;
+				const float ln = len3(d);
+				const float a = ln * ln;                                                 // ray.cl:73 pow(length(d),2)
+				bool hit = false;
+				float distance = 0.0f;
+				int idx = 0;
+				for(int i = 0; i < p.n; i++) {                                           // ray.cl:101-110
+					const float4 g = sc.geom[i];
+					const f3 oc = sub3(o, mk3(g.x, g.y, g.z));
+					const float bHalf = dot3(oc, d);
+					const float c = oc.x * oc.x + oc.y * oc.y + oc.z * oc.z - g.w;
+					const float disc = bHalf * bHalf - a * c;
+					if(!(disc < 0.0f)) {
+						const float t = (-bHalf - sqrtf(disc)) / a;
+						if(t > 0.0f && (!hit || t < distance)) { hit = true; distance = t; idx = i; }
+					}
+				}
+				if(!hit) { color = mul3(mask, mk3(p.bgx, p.bgy, p.bgz)); break; }      // ray.cl:112-115
+				const float4 g = sc.geom[idx];
+				const float4 mA = sc.matA[idx];
+				const float4 mB = sc.matB[idx];
+				const int type = __float_as_int(mA.w);
+				const f3 mcol = mk3(mA.x, mA.y, mA.z);
+				const f3 hitPos = add3(o, scl3(d, distance));                            // ray.cl:117
+				f3 normal = norm3(sub3(hitPos, mk3(g.x, g.y, g.z)));                     // ray.cl:118
+				const f3 offPos = sub3(hitPos, scl3(normal, 0.0001f));                   // ray.cl:119
+				bool front = true;
+				if(dot3(d, normal) > 0.0f) { front = false; normal = scl3(normal, -1.0f); }   // ray.cl:122-128
+				if(type == 0) {                                                          // ray.cl:130-134
+					if(front) { color = mul3(mask, mcol); break; }
+				} else if(type == 1) {                                                   // ray.cl:136-141
+					if(front) {
+						d = add3(normal, random_unit_vector(rng));
+						o = offPos;
+						mask = mul3(mask, mcol);
+					}
+				} else if(type == 2) {                                                   // ray.cl:143-148
+					if(front) {
+						d = add3(reflection_dir(d, normal), scl3(random_unit_vector(rng), mB.y));
+						o = offPos;
+						mask = add3(scl3(mask, 1.0f - mB.x), scl3(mul3(mask, mcol), mB.x));
+					}
+				} else if(type == 3) {                                                   // ray.cl:150-171
+					const float rel = front ? mB.z : 1.0f / mB.z;
+					const float cosTheta = fminf(dot3(scl3(d, -1.0f), normal), 1.0f);
+					const float sinTheta = sqrtf(1.0f - cosTheta * cosTheta);
+					bool reflect = rel * sinTheta > 1.0f;
+					if(!reflect) reflect = reflectance(cosTheta, rel) > rand_float(rng);    // short-circuit draw, ray.cl:163
+					const f3 base = reflect ? reflection_dir(d, normal) : refraction_dir(d, normal, rel);
+					d = add3(base, scl3(random_unit_vector(rng), mB.y));
+					o = offPos;
+					mask = add3(scl3(mask, 1.0f - mB.x), scl3(mul3(mask, mcol), mB.x));
+				}
+			}
+			color = scl3(scl3(color, p.exposure), p.aperture);                           // main.cl:27
+			const float f = (float)(p.firstFrame + k), f1 = (float)(p.firstFrame + k + 1);
+			acc = mk3((acc.x * f + color.x) / f1, (acc.y * f + color.y) / f1, (acc.z * f + color.z) / f1);   // main.cl:29
+		}
+		image[id] = make_float4(acc.x, acc.y, acc.z, 0.0f);
+	}
+	if(COUNT) {
+		// wave-level sum, one atomic per wave
+		unsigned int v = myBounces;
+		for(int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+		if((threadIdx.x & 63) == 0 && v) atomicAdd(bounceCounter, (unsigned long long)v);
+	}
+}
+
+// ---------------------------------------------------------------------------------------
+// Epilogue: gamma (sqrt), clamp, (int)(x*255) truncation -> packed RGB8
+// (src/c/renderer.c:50-56, 17-39).  sqrtf == (float)sqrt((double)x) for every float.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pt_to_u8_kernel(const float4 *__restrict__ image, int pixels, unsigned char *__restrict__ out) {
+	int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+	if(i >= pixels) return;
+	float4 v = image[i];
+	float c[3] = {v.x, v.y, v.z};
+#pragma unroll
+	for(int k = 0; k < 3; k++) {
+		float x = sqrtf(c[k]);
+		if(x < 0.0f) x = 0.0f;
+		if(x > 1.0f) x = 1.0f;
+		out[3 * (size_t)i + k] = (unsigned char)(int)(x * 255.0f);
+	}
+}
+
+// ---------------------------------------------------------------------------------------
+// Self-test kernel (pt_selftest in pt_hip.h)
+// ---------------------------------------------------------------------------------------
+__global__ void pt_selftest_kernel(int op, const uint64_t *a, const uint64_t *b, const float *inf_, int n, uint64_t *ou, float *of) {
+	int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+	if(i >= n) return;
+	if(op == 0) {
+		ou[i] = init_rng_2((uint32_t)a[i], 16807ull * b[i]);
+	} else if(op == 1) {
+		uint32_t s = (uint32_t)a[i];
+		of[i] = rand_float(s);
+		ou[i] = s;
+	} else if(op == 2) {
+		uint32_t s = (uint32_t)a[i];
+		f3 r = random_unit_vector(s);
+		of[3 * i] = r.x; of[3 * i + 1] = r.y; of[3 * i + 2] = r.z;
+		ou[i] = s;
+	} else if(op == 3) {
+		float x = inf_[2 * i], y = inf_[2 * i + 1];
+		of[4 * i] = x / y;
+		of[4 * i + 1] = sqrtf(x);
+		of[4 * i + 2] = reflectance(x, y);
+		of[4 * i + 3] = pow5(x);
+	}
+}
+
+// ---------------------------------------------------------------------------------------
+// Host side of the C ABI
+// ---------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char *fmt, const char *detail) {
+	snprintf(g_err, sizeof g_err, fmt, detail ? detail : "");
+	return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+	do {                                                                                       \
+		hipError_t e_ = (expr);                                                                \
+		if(e_ != hipSuccess) {                                                                 \
+			snprintf(g_err, sizeof g_err, "%s failed: %s", #expr, hipGetErrorString(e_));      \
+			return e_ == hipErrorOutOfMemory ? PT_E_NOMEM : PT_E_DEVICE;                       \
+		}                                                                                      \
+	} while(0)
+
+struct pt_ctx {
+	int device;
+	hipStream_t stream;
+	float4 *image; int imgW, imgH;
+	float4 *geom, *matA, *matB; int nSpheres, capSpheres;
+	uint64_t *seedmul; int capSeeds;
+	unsigned long long *counter;
+	unsigned char *u8; size_t capU8;
+};
+
+extern "C" const char *pt_last_error(void) { return g_err; }
+
+extern "C" int pt_device_count(int *count) {
+	if(!count) return fail(PT_E_INVALID, "pt_device_count: NULL%s", NULL);
+	int n = 0;
+	hipError_t e = hipGetDeviceCount(&n);
+	if(e != hipSuccess) { *count = 0; return fail(PT_E_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e)); }
+	*count = n;
+	return PT_OK;
+}
+
+extern "C" int pt_ctx_create(int device, pt_ctx **out) {
+	if(!out) return fail(PT_E_INVALID, "pt_ctx_create: NULL out%s", NULL);
+	*out = NULL;
+	int n = 0;
+	HIP_TRY(hipGetDeviceCount(&n));
+	if(device < 0 || device >= n) return fail(PT_E_INVALID, "pt_ctx_create: device out of range%s", NULL);
+	HIP_TRY(hipSetDevice(device));
+	pt_ctx *c = (pt_ctx *)calloc(1, sizeof(pt_ctx));
+	if(!c) return fail(PT_E_NOMEM, "pt_ctx_create: host allocation failed%s", NULL);
+	c->device = device;
+	HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+	HIP_TRY(hipMalloc((void **)&c->counter, sizeof(unsigned long long)));
+	*out = c;
+	return PT_OK;
+}
+
+extern "C" int pt_ctx_destroy(pt_ctx *c) {
+	if(!c) return PT_OK;
+	(void)hipSetDevice(c->device);
+	(void)hipStreamSynchronize(c->stream);
+	(void)hipFree(c->image); (void)hipFree(c->geom); (void)hipFree(c->matA); (void)hipFree(c->matB);
+	(void)hipFree(c->seedmul); (void)hipFree(c->counter); (void)hipFree(c->u8);
+	(void)hipStreamDestroy(c->stream);
+	free(c);
+	return PT_OK;
+}
+
+extern "C" int pt_image_alloc(pt_ctx *c, int width, int height) {
+	if(!c || width <= 0 || height <= 0 || (long long)width * height > (1ll << 30))
+		return fail(PT_E_INVALID, "pt_image_alloc: bad size%s", NULL);
+	HIP_TRY(hipSetDevice(c->device));
+	if(c->image) { HIP_TRY(hipFree(c->image)); c->image = NULL; }
+	size_t bytes = sizeof(float4) * (size_t)width * (size_t)height;
+	HIP_TRY(hipMalloc((void **)&c->image, bytes));
+	HIP_TRY(hipMemsetAsync(c->image, 0, bytes, c->stream));
+	c->imgW = width; c->imgH = height;
+	return PT_OK;
+}
+
+extern "C" int pt_scene_upload(pt_ctx *c, const float *spheres, int n) {
+	if(!c || n < 0 || (n > 0 && !spheres)) return fail(PT_E_INVALID, "pt_scene_upload: bad arguments%s", NULL);
+	HIP_TRY(hipSetDevice(c->device));
+	if(n > c->capSpheres) {
+		(void)hipFree(c->geom); (void)hipFree(c->matA); (void)hipFree(c->matB);
+		c->geom = c->matA = c->matB = NULL; c->capSpheres = 0;
+		HIP_TRY(hipMalloc((void **)&c->geom, sizeof(float4) * (size_t)n));
+		HIP_TRY(hipMalloc((void **)&c->matA, sizeof(float4) * (size_t)n));
+		HIP_TRY(hipMalloc((void **)&c->matB, sizeof(float4) * (size_t)n));
+		c->capSpheres = n;
+	}
+	c->nSpheres = n;
+	if(n == 0) return PT_OK;
+	float4 *h = (float4 *)malloc(sizeof(float4) * 3 * (size_t)n);
+	if(!h) return fail(PT_E_NOMEM, "pt_scene_upload: host allocation failed%s", NULL);
+	float4 *hg = h, *ha = h + n, *hb = h + 2 * (size_t)n;
+	for(int i = 0; i < n; i++) {
+		const float *r = spheres + PT_SPHERE_FLOATS * (size_t)i;
+		// r*r is rounded once here exactly as `sphere.radius * sphere.radius` is per test (src/cl/ray.cl:75)
+		volatile float r2 = r[3] * r[3];
+		hg[i] = make_float4(r[0], r[1], r[2], r2);
+		int type = (int)r[4];
+		float tb;
+		memcpy(&tb, &type, 4);
+		ha[i] = make_float4(r[5], r[6], r[7], tb);
+		hb[i] = make_float4(r[8], r[9], r[10], 0.0f);
+	}
+	// one stream, in order; the staging buffer is freed after the copies have completed
+	hipError_t e1 = hipMemcpyAsync(c->geom, hg, sizeof(float4) * (size_t)n, hipMemcpyHostToDevice, c->stream);
+	hipError_t e2 = hipMemcpyAsync(c->matA, ha, sizeof(float4) * (size_t)n, hipMemcpyHostToDevice, c->stream);
+	hipError_t e3 = hipMemcpyAsync(c->matB, hb, sizeof(float4) * (size_t)n, hipMemcpyHostToDevice, c->stream);
+	hipError_t e4 = hipStreamSynchronize(c->stream);
+	free(h);
+	HIP_TRY(e1); HIP_TRY(e2); HIP_TRY(e3); HIP_TRY(e4);
+	return PT_OK;
+}
+
+static int local_rows(int H, int rank, int world, int band) {
+	// rows r with (r / band) % world == rank
+	int rows = 0;
+	int nb = (H + band - 1) / band;
+	for(int b = rank; b < nb; b += world) {
+		int lo = b * band, hi = lo + band < H ? lo + band : H;
+		rows += hi - lo;
+	}
+	return rows;
+}
+
+extern "C" int pt_render(pt_ctx *c, const pt_render_args *a) {
+	if(!c || !a) return fail(PT_E_INVALID, "pt_render: NULL%s", NULL);
+	if(a->width <= 0 || a->height <= 0 || a->max_depth < 0 || a->n_frames < 0 || a->first_frame < 0)
+		return fail(PT_E_INVALID, "pt_render: bad image/sample arguments%s", NULL);
+	if((long long)a->width * a->height > (1ll << 30)) return fail(PT_E_INVALID, "pt_render: image too large%s", NULL);
+	if(a->world < 1 || a->rank < 0 || a->rank >= a->world || a->band_rows < 1)
+		return fail(PT_E_INVALID, "pt_render: bad partition (rank/world/band_rows)%s", NULL);
+	if(a->n_frames > 0 && !a->seeds) return fail(PT_E_INVALID, "pt_render: NULL seeds%s", NULL);
+	float4 *img = (float4 *)a->d_image;
+	if(!img) {
+		if(!c->image || c->imgW != a->width || c->imgH != a->height)
+			return fail(PT_E_STATE, "pt_render: no accumulator of this size (call pt_image_alloc)%s", NULL);
+		img = c->image;
+	}
+	HIP_TRY(hipSetDevice(c->device));
+	hipStream_t st = a->stream ? (hipStream_t)a->stream : c->stream;
+	if(a->n_frames == 0) return PT_OK;
+
+	if(a->n_frames > c->capSeeds) {
+		if(c->seedmul) { HIP_TRY(hipFree(c->seedmul)); c->seedmul = NULL; c->capSeeds = 0; }
+		int cap = a->n_frames < 256 ? 256 : a->n_frames;
+		HIP_TRY(hipMalloc((void **)&c->seedmul, sizeof(uint64_t) * (size_t)cap));
+		c->capSeeds = cap;
+	}
+	uint64_t *hs = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)a->n_frames);
+	if(!hs) return fail(PT_E_NOMEM, "pt_render: host allocation failed%s", NULL);
+	for(int k = 0; k < a->n_frames; k++) hs[k] = 16807ull * a->seeds[k];     // src/cl/rng.cl:8, folded per sample
+	hipError_t ec = hipMemcpyAsync(c->seedmul, hs, sizeof(uint64_t) * (size_t)a->n_frames, hipMemcpyHostToDevice, st);
+	hipError_t es = hipStreamSynchronize(st);   // pageable staging buffer: finish the copy before freeing it
+	free(hs);
+	HIP_TRY(ec); HIP_TRY(es);
+
+	KParams p;
+	p.W = a->width; p.H = a->height; p.maxDepth = a->max_depth; p.n = c->nSpheres;
+	p.bgx = a->background[0]; p.bgy = a->background[1]; p.bgz = a->background[2];
+	p.px = a->cam_pos[0]; p.py = a->cam_pos[1]; p.pz = a->cam_pos[2];
+	// cos/sin of the launch-uniform camera angles: the host libm, as the oracle uses (src/cl/ray.cl:45-49)
+	p.cosRx = cosf(a->cam_rot[0]); p.sinRx = sinf(a->cam_rot[0]);
+	p.cosRy = cosf(a->cam_rot[1]); p.sinRy = sinf(a->cam_rot[1]);
+	p.sensorWidth = a->sensor_width; p.focalLength = a->focal_length; p.aperture = a->aperture; p.exposure = a->exposure;
+	p.firstFrame = a->first_frame; p.nFrames = a->n_frames;
+	p.rank = a->rank; p.world = a->world; p.bandRows = a->band_rows;
+	long long lp = (long long)local_rows(a->height, a->rank, a->world, a->band_rows) * a->width;
+	p.localPixels = (int)lp;
+	if(lp == 0) return PT_OK;
+
+	SceneTables sc = {c->geom, c->matA, c->matB};
+	dim3 block(256), grid((unsigned)((lp + 255) / 256));
+	if(a->bounce_count) {
+		HIP_TRY(hipMemsetAsync(c->counter, 0, sizeof(unsigned long long), st));
+		hipLaunchKernelGGL(pt_render_kernel<true>, grid, block, 0, st, img, p, sc, c->seedmul, c->counter);
+		HIP_TRY(hipGetLastError());
+		unsigned long long v = 0;
+		HIP_TRY(hipMemcpyAsync(&v, c->counter, sizeof v, hipMemcpyDeviceToHost, st));
+		HIP_TRY(hipStreamSynchronize(st));
+		*a->bounce_count = (uint64_t)v;
+		return PT_OK;
+	}
+	hipLaunchKernelGGL(pt_render_kernel<false>, grid, block, 0, st, img, p, sc, c->seedmul, c->counter);
+	HIP_TRY(hipGetLastError());
+	if(!a->async) HIP_TRY(hipStreamSynchronize(st));
+	return PT_OK;
+}
+
+extern "C" int pt_sync(pt_ctx *c) {
+	if(!c) return fail(PT_E_INVALID, "pt_sync: NULL%s", NULL);
+	HIP_TRY(hipSetDevice(c->device));
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	return PT_OK;
+}
+
+extern "C" int pt_image_read(pt_ctx *c, float *host_rgba) {
+	if(!c || !host_rgba) return fail(PT_E_INVALID, "pt_image_read: NULL%s", NULL);
+	if(!c->image) return fail(PT_E_STATE, "pt_image_read: no accumulator (call pt_image_alloc)%s", NULL);
+	HIP_TRY(hipSetDevice(c->device));
+	HIP_TRY(hipMemcpyAsync(host_rgba, c->image, sizeof(float4) * (size_t)c->imgW * c->imgH, hipMemcpyDeviceToHost, c->stream));
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	return PT_OK;
+}
+
+extern "C" int pt_image_read_u8(pt_ctx *c, const void *d_image, int width, int height, unsigned char *host_rgb) {
+	if(!c || !host_rgb) return fail(PT_E_INVALID, "pt_image_read_u8: NULL%s", NULL);
+	const float4 *img = (const float4 *)d_image;
+	if(!img) {
+		if(!c->image) return fail(PT_E_STATE, "pt_image_read_u8: no accumulator (call pt_image_alloc)%s", NULL);
+		img = c->image; width = c->imgW; height = c->imgH;
+	}
+	if(width <= 0 || height <= 0) return fail(PT_E_INVALID, "pt_image_read_u8: bad size%s", NULL);
+	HIP_TRY(hipSetDevice(c->device));
+	size_t pixels = (size_t)width * height, bytes = 3 * pixels;
+	if(bytes > c->capU8) {
+		if(c->u8) { HIP_TRY(hipFree(c->u8)); c->u8 = NULL; c->capU8 = 0; }
+		HIP_TRY(hipMalloc((void **)&c->u8, bytes));
+		c->capU8 = bytes;
+	}
+	hipLaunchKernelGGL(pt_to_u8_kernel, dim3((unsigned)((pixels + 255) / 256)), dim3(256), 0, c->stream, img, (int)pixels, c->u8);
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipMemcpyAsync(host_rgb, c->u8, bytes, hipMemcpyDeviceToHost, c->stream));
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	return PT_OK;
+}
+
+extern "C" int pt_selftest(pt_ctx *c, int op, const uint64_t *a, const uint64_t *b, const float *in_f, int n,
+                           uint64_t *out_u64, float *out_f) {
+	if(!c || n <= 0 || op < 0 || op > 3) return fail(PT_E_INVALID, "pt_selftest: bad arguments%s", NULL);
+	HIP_TRY(hipSetDevice(c->device));
+	uint64_t *da = NULL, *db = NULL, *dou = NULL;
+	float *dif = NULL, *dof = NULL;
+	size_t nu = sizeof(uint64_t) * (size_t)n;
+	int rc = PT_OK;
+	hipError_t e;
+#define ST_TRY(x) do { e = (x); if(e != hipSuccess) { snprintf(g_err, sizeof g_err, "%s failed: %s", #x, hipGetErrorString(e)); rc = PT_E_DEVICE; goto done; } } while(0)
+	ST_TRY(hipMalloc((void **)&da, nu));
+	ST_TRY(hipMalloc((void **)&db, nu));
+	ST_TRY(hipMalloc((void **)&dou, nu));
+	ST_TRY(hipMalloc((void **)&dif, sizeof(float) * 2 * (size_t)n));
+	ST_TRY(hipMalloc((void **)&dof, sizeof(float) * 4 * (size_t)n));
+	ST_TRY(hipMemset(dou, 0, nu));
+	ST_TRY(hipMemset(dof, 0, sizeof(float) * 4 * (size_t)n));
+	if(a) ST_TRY(hipMemcpy(da, a, nu, hipMemcpyHostToDevice));
+	if(b) ST_TRY(hipMemcpy(db, b, nu, hipMemcpyHostToDevice));
+	if(in_f) ST_TRY(hipMemcpy(dif, in_f, sizeof(float) * 2 * (size_t)n, hipMemcpyHostToDevice));
+	hipLaunchKernelGGL(pt_selftest_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, op, da, db, dif, n, dou, dof);
+	ST_TRY(hipGetLastError());
+	ST_TRY(hipStreamSynchronize(c->stream));
+	if(out_u64) ST_TRY(hipMemcpy(out_u64, dou, nu, hipMemcpyDeviceToHost));
+	if(out_f) ST_TRY(hipMemcpy(out_f, dof, sizeof(float) * 4 * (size_t)n, hipMemcpyDeviceToHost));
+done:
+	(void)hipFree(da); (void)hipFree(db); (void)hipFree(dou); (void)hipFree(dif); (void)hipFree(dof);
+	return rc;
+#undef ST_TRY
+}

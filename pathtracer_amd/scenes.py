@@ -1,0 +1,153 @@
+"""Scene descriptions used by bench.py, the tests and the C scene driver's Python twin.
+
+A scene is a plain dict of numpy arrays in the interchange layout every layer of this
+repo shares (oracle/, the C ABI in include/pt_hip.h, tests/):
+
+    spheres : float32 [N, 12] = cx cy cz radius | type colr colg colb | tint fuzz refIdx 0
+              (type 0 light, 1 lambert, 2 metal, 3 dielectric — the codes of
+              /root/reference/src/c/renderer.c:119-133)
+    bg      : float32 [3]     background colour   (renderer.c:115-117)
+    cam     : float32 [10]    pos3 rot3 sensorWidth focalLength aperture exposure (renderer.c:147-151)
+
+Insertion order is kept: the closest-hit scan breaks ties towards the lowest index
+(/root/reference/src/cl/ray.cl:101-110).
+"""
+import math
+
+import numpy as np
+
+LIGHT, LAMBERT, METAL, DIELECTRIC = 0, 1, 2, 3
+
+
+def _sphere(x, y, z, r, mat):
+    t, cr, cg, cb, tint, fuzz, ref = mat
+    return [x, y, z, r, float(t), cr, cg, cb, tint, fuzz, ref, 0.0]
+
+
+def lambertian(r, g, b):
+    return (LAMBERT, r, g, b, 0.0, 0.0, 0.0)
+
+
+def metal(r, g, b, tint, fuzz):
+    return (METAL, r, g, b, tint, fuzz, 0.0)
+
+
+def dielectric(r, g, b, tint, fuzz, ref_idx):
+    return (DIELECTRIC, r, g, b, tint, fuzz, ref_idx)
+
+
+def light_source(r, g, b):
+    return (LIGHT, r, g, b, 0.0, 0.0, 0.0)
+
+
+def _pack(spheres, bg, cam):
+    # Lua numbers are doubles, narrowed to float at the binding
+    # (/root/reference/src/c/lua_wrapper.c:166-188) — np.float32() does the same narrowing.
+    return {
+        "spheres": np.asarray(spheres, dtype=np.float64).astype(np.float32).reshape(-1, 12),
+        "bg": np.asarray(bg, dtype=np.float64).astype(np.float32),
+        "cam": np.asarray(cam, dtype=np.float64).astype(np.float32),
+    }
+
+
+def main_lua_frame(i=0, frames=300):
+    """Scene of animation frame `i` of /root/reference/scripts/main.lua:2-94."""
+    wall = 10000.0
+    white, red, green = lambertian(1, 1, 1), lambertian(1, 0, 0), lambertian(0, 1, 0)
+    light = light_source(10, 10, 10)
+    mirror = metal(0, 0, 0, 0, 0)
+    green_glass = dielectric(0, 1, 0, 0.8, 0, 0.95)
+    s = [
+        _sphere(0, wall + 6, -10, wall, white),
+        _sphere(0, -(wall + 6), -10, wall, white),
+        _sphere(0, 0, -(wall + 20), wall, white),
+        _sphere(0, 0, (wall + 20), wall, white),
+        _sphere(wall + 6, 0, -5, wall, green),
+        _sphere(-(wall + 6), 0, -5, wall, red),
+        _sphere(-1, 0, -10, 1, green_glass),
+    ]
+    cx, cy, cz = -1.0, 0.0, -10.0
+    ph = 2 * math.pi * (i / frames)
+    s.append(_sphere(cx + 2 * math.cos(ph), cy + math.sin(ph), cz + 2 * math.sin(ph), 0.5, light))
+    ph2 = -4 * math.pi * (i / frames)
+    s.append(_sphere(cx + 3.5 * math.cos(ph2), cy + 0, cz + 3.5 * math.sin(ph2), 1, mirror))
+    start = 3 * math.pi / 4
+    cam = [cx + 0, cy + 5 * math.cos(ph + start), cz + 5 * math.sin(ph + start),
+           ph - math.pi / 2 + start, 0, 0, 15, 20, 0.001, 1000]
+    return _pack(s, [0, 0, 0], cam)
+
+
+class _Lcg64:
+    """Fixed 64-bit LCG (Knuth MMIX constants) — our own generator, so the synthetic
+    scenes are reproducible without libc."""
+
+    def __init__(self, seed):
+        self.s = seed & 0xFFFFFFFFFFFFFFFF
+
+    def u01(self):
+        self.s = (self.s * 6364136223846793005 + 1442695040888963407) & 0xFFFFFFFFFFFFFFFF
+        return (self.s >> 11) / float(1 << 53)
+
+    def uniform(self, a, b):
+        return a + (b - a) * self.u01()
+
+
+def dense_random(n=10000, seed=12345):
+    """Config 3 — intersection stress: n random spheres in [-50,50]^3 under a sky."""
+    g = _Lcg64(seed)
+    s = []
+    for _ in range(n):
+        x, y, z = g.uniform(-50, 50), g.uniform(-50, 50), g.uniform(-50, 50)
+        r = g.uniform(0.1, 1.0)
+        m = g.u01()
+        cr, cg, cb = g.u01(), g.u01(), g.u01()
+        if m < 0.70:
+            mat = lambertian(cr, cg, cb)
+        elif m < 0.85:
+            mat = metal(cr, cg, cb, g.u01(), 0.3 * g.u01())
+        elif m < 0.95:
+            mat = dielectric(cr, cg, cb, 0.5 * g.u01(), 0.0, 1.5)
+        else:
+            mat = light_source(10 * cr, 10 * cg, 10 * cb)
+        s.append(_sphere(x, y, z, r, mat))
+    cam = [0, 0, 120, 0, 0, 0, 15, 20, 0.001, 1000]
+    return _pack(s, [0.5, 0.7, 1.0], cam)
+
+
+def glass_lattice():
+    """Config 5 — divergence stress: the frame-0 box with the glass sphere replaced by a
+    3x3x3 lattice of dielectric spheres and four small emissive spheres (depth 32)."""
+    base = main_lua_frame(0)
+    keep = [row for k, row in enumerate(base["spheres"].tolist()) if k != 6]
+    glass = dielectric(1, 1, 1, 0.2, 0, 1.5)
+    for ix in (-1, 0, 1):
+        for iy in (-1, 0, 1):
+            for iz in (-1, 0, 1):
+                keep.append(_sphere(-1 + 0.9 * ix, 0.9 * iy, -10 + 0.9 * iz, 0.4, glass))
+    for (x, y, z) in ((-3.5, 2.5, -11), (2.0, -2.5, -9), (-2.5, -2.0, -13), (1.5, 3.0, -12)):
+        keep.append(_sphere(x, y, z, 0.3, light_source(10, 8, 6)))
+    return {"spheres": np.asarray(keep, dtype=np.float32), "bg": base["bg"], "cam": base["cam"]}
+
+
+def material_micro(kind):
+    """One sphere of one material under a bright sky — one scene per shading branch."""
+    mats = {
+        "light": light_source(4, 3, 2),
+        "lambert": lambertian(0.8, 0.6, 0.4),
+        "metal": metal(0.9, 0.7, 0.5, 0.6, 0.25),
+        "dielectric": dielectric(0.6, 0.9, 0.7, 0.5, 0.1, 1.5),
+        "dielectric_low": dielectric(0.2, 1.0, 0.3, 0.8, 0.0, 0.95),
+    }
+    s = [
+        _sphere(0, 0, -6, 1.5, mats[kind]),
+        _sphere(0, -1001.5, -6, 1000, lambertian(0.5, 0.5, 0.5)),
+    ]
+    cam = [0, 0.5, 0, 0.05, 0.1, 0.3, 4, 5, 0.01, 100]
+    return _pack(s, [0.6, 0.7, 0.9], cam)
+
+
+def empty():
+    """No spheres: every path misses on its first bounce and returns the background."""
+    cam = [0, 0, 0, 0, 0, 0, 15, 20, 0.001, 1000]
+    return {"spheres": np.zeros((0, 12), np.float32), "bg": np.asarray([0.25, 0.5, 0.75], np.float32),
+            "cam": np.asarray(cam, np.float32)}

@@ -1,0 +1,22 @@
+"""Parity cases shared by the golden-fixture generator, the oracle tests and the GPU tests."""
+from pathtracer_amd import scenes
+
+# name -> (scene factory, W, H, max_depth, spp)
+CASES = {
+    "frame0_64x36": (lambda: scenes.main_lua_frame(0), 64, 36, 50, 16),
+    "frame0_256": (lambda: scenes.main_lua_frame(0), 256, 256, 50, 16),     # BASELINE config 1
+    "frame77_96x54": (lambda: scenes.main_lua_frame(77), 96, 54, 50, 8),
+    "frame211_80x45": (lambda: scenes.main_lua_frame(211), 80, 45, 50, 8),
+    "lattice_96x54": (scenes.glass_lattice, 96, 54, 32, 8),                 # config 5 scene, small
+    "dense500_96x54": (lambda: scenes.dense_random(500), 96, 54, 50, 4),    # config 3 generator, small
+    "dense3000_64x36": (lambda: scenes.dense_random(3000), 64, 36, 50, 2),
+    "empty_33x17": (scenes.empty, 33, 17, 50, 3),                           # no spheres, ragged size
+    "light_64x48": (lambda: scenes.material_micro("light"), 64, 48, 50, 8),
+    "lambert_64x48": (lambda: scenes.material_micro("lambert"), 64, 48, 50, 8),
+    "metal_64x48": (lambda: scenes.material_micro("metal"), 64, 48, 50, 8),
+    "dielectric_64x48": (lambda: scenes.material_micro("dielectric"), 64, 48, 50, 8),
+    "dielectric_low_64x48": (lambda: scenes.material_micro("dielectric_low"), 64, 48, 50, 8),
+    "depth0_16x16": (lambda: scenes.main_lua_frame(0), 16, 16, 0, 2),       # maxDepth 0: loop never runs -> black
+    "depth1_32x32": (lambda: scenes.main_lua_frame(3), 32, 32, 1, 4),
+    "one_pixel": (lambda: scenes.main_lua_frame(0), 1, 1, 50, 4),           # id 0: RNG stuck at 0
+}
