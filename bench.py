@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""bench.py — Msamples/s of the path-tracing hot path on N MI355X GPUs.
+
+Workload (BASELINE.json configs[1]): the frame-0 scene of the reference's scripts/main.lua,
+1920x1080, 256 spp, max depth 50, seeds = the first 256 values of glibc rand() — exactly what the
+reference's render() would run (src/c/renderer.c:153-262).  One step = one whole render of that
+image: W*H*spp samples.  Scene, seeds and accumulator are resident on the GPU when the timed
+region starts; the per-step host->device traffic is the 2 KB seed table.
+
+N = 1 : python bench.py [--steps K --warmup W]
+N > 1 : python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N
+        one process per GPU; the SAME image is cut into 8-row bands dealt round-robin to the ranks
+        (work-item ids stay global, so every pixel is bit-identical to the 1-GPU image), each rank
+        renders its bands into a zeroed full-frame buffer and one RCCL reduce(sum) over xGMI
+        combines them on rank 0 — inside the timed step.  Fixed total work: "scaling": "strong".
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+WIDTH, HEIGHT, SPP, DEPTH = 1920, 1080, 256, 50
+BAND_ROWS = 8
+PEAK_FP32_VALU_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: 256 CU x 4 SIMD x 64 FLOP/clk x 2.4 GHz
+MBAR_DEFAULT_SCENE = 30.0          # mean material FLOPs per bounce, default scene
+
+
+def flops_per_sample(bounces_per_sample, n_spheres, mbar=MBAR_DEFAULT_SCENE):
+    """FLOPs/sample = B*(18*N + 34 + Mbar) + 60 (algorithmic, reference arithmetic)."""
+    return bounces_per_sample * (18.0 * n_spheres + 34.0 + mbar) + 60.0
+
+
+def cpu_baseline(scene, seeds):
+    """The reference kernel (x86 build, oracle/_ref) or, where that is absent, the oracle port, timed
+    on the host cores on a bounded sample of the same workload: every pixel of the 1080p image at the
+    first 4 of its 256 samples (8.3 M samples)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+    cores = min(16, os.cpu_count() or 1)
+    spp = 4
+    if oracle_lib.have_ref("fast"):
+        lib, kind = oracle_lib.load_ref("fast"), "reference"
+    else:
+        lib, kind = oracle_lib.load_oracle(), "port"
+    t0 = time.perf_counter()
+    lib.render(scene, WIDTH, HEIGHT, DEPTH, seeds[:spp], nthreads=cores)
+    dt = time.perf_counter() - t0
+    return {"value": WIDTH * HEIGHT * spp / dt / 1e6, "unit": "Msamples/s", "cores": cores, "kind": kind,
+            "sample": "all %dx%d pixels at the first %d of %d spp (%.1f M samples, %.1f s)" %
+                      (WIDTH, HEIGHT, spp, SPP, WIDTH * HEIGHT * spp / 1e6, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--spp", type=int, default=SPP, help="debug only: any value but %d is not the benchmark" % SPP)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from pathtracer_amd import hip, scenes, seeds as seedmod
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch N>1 with torch.distributed.run)" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py: no GPU visible — this benchmark has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    spp = args.spp
+    scene = scenes.main_lua_frame(0)
+    seeds = seedmod.glibc_rand_stream(spp)
+    n_spheres = scene["spheres"].shape[0]
+
+    ctx = hip.Context(local_rank)
+    ctx.scene_upload(scene["spheres"])
+    frame = torch.zeros((HEIGHT, WIDTH, 4), dtype=torch.float32, device=dev)
+    # One explicit (non-null) HIP stream carries everything: the render kernel (launched by the C ABI
+    # on this handle), the zero-fill, the RCCL reduce and the timing events.  torch's default stream
+    # has handle 0, which the C ABI reads as "use the context's own stream".
+    side = torch.cuda.Stream(device=dev)
+    torch.cuda.synchronize()
+    torch.cuda.set_stream(side)
+    stream = side.cuda_stream
+    assert stream != 0
+
+    def step(count=False):
+        if world > 1:
+            frame.zero_()
+        bc = ctx.render(scene, WIDTH, HEIGHT, DEPTH, seeds, rank=rank, world=world, band_rows=BAND_ROWS,
+                        d_image=frame.data_ptr(), stream=stream, count_bounces=count, async_=True)
+        if world > 1:
+            dist.reduce(frame, dst=0, op=dist.ReduceOp.SUM)
+        return bc
+
+    # untimed: bounce-loop iterations of this rank's share (deterministic given the seeds) for the FLOP count
+    my_bounces = step(count=True)
+    for _ in range(args.warmup):
+        step()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        if world > 1:
+            frame.zero_()
+        ev[k][0].record()
+        ctx.render(scene, WIDTH, HEIGHT, DEPTH, seeds, rank=rank, world=world, band_rows=BAND_ROWS,
+                   d_image=frame.data_ptr(), stream=stream, async_=True)
+        ev[k][1].record()
+        if world > 1:
+            dist.reduce(frame, dst=0, op=dist.ReduceOp.SUM)
+    barrier()
+    dt = time.perf_counter() - t0
+
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    tb = torch.tensor([float(my_bounces), dt, kern_ms], dtype=torch.float64, device=dev)
+    if world > 1:
+        tsum = tb.clone()
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        tmax = tb.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        total_bounces, dt, kern_ms_max = float(tsum[0]), float(tmax[1]), float(tmax[2])
+    else:
+        total_bounces, kern_ms_max = float(my_bounces), kern_ms
+
+    if rank == 0:
+        samples = WIDTH * HEIGHT * spp
+        bps = total_bounces / samples
+        fps = flops_per_sample(bps, n_spheres)
+        # dominant kernel = pt_render_kernel; this rank's launch processes its share of the samples
+        my_samples = samples if world == 1 else float(my_bounces) / bps
+        achieved = fps * my_samples / (kern_ms * 1e-3) / 1e12
+        out = {
+            "metric": "Msamples/sec at 1080p",
+            "value": samples * args.steps / dt / 1e6,
+            "unit": "Msamples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "main.lua frame-0 scene 1920x1080 %d spp depth 50 (BASELINE configs[1])" % spp,
+                       "spheres": n_spheres, "seeds": "glibc rand() stream, first %d values" % spp,
+                       "partition": "1 GPU" if world == 1 else "%d-row bands round-robin over %d ranks + RCCL reduce" % (BAND_ROWS, world),
+                       "bounces_per_sample": round(bps, 3)},
+            "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_FP32_VALU_TFLOPS, "traffic": None,
+                         "kernel": "pt_render_kernel", "kernel_ms": kern_ms,
+                         "flops_per_sample": round(fps, 1),
+                         "note": "FP32 vector roofline (no dense contraction on this path, SURVEY.md §8d); "
+                                 "algorithmic FLOPs = B*(18N+34+30)+60 per sample with B measured in-kernel"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(scene, seedmod.glibc_rand_stream(SPP))
+        print(json.dumps(out), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

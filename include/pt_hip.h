@@ -61,6 +61,9 @@ typedef struct pt_render_args {
 	                             synchronisation.  NULL: not counted. */
 	int async;                /* 0: return after the kernel has finished (the reference's clFinish,
 	                             src/c/renderer.c:251).  1: return after enqueue. */
+	float *kernel_ms;         /* optional HOST out: duration of the render kernel in ms, from HIP events
+	                             recorded on the launch stream around the launch.  Forces a
+	                             synchronisation.  NULL: not timed. */
 } pt_render_args;
 
 /* Text of the last error on this thread ("" if none). */

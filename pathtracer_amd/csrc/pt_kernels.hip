@@ -227,6 +227,7 @@ struct pt_ctx {
 	uint64_t *seedmul; int capSeeds;
 	unsigned long long *counter;
 	unsigned char *u8; size_t capU8;
+	hipEvent_t evStart, evStop;
 };
 
 extern "C" const char *pt_last_error(void) { return g_err; }
@@ -252,6 +253,8 @@ extern "C" int pt_ctx_create(int device, pt_ctx **out) {
 	c->device = device;
 	HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
 	HIP_TRY(hipMalloc((void **)&c->counter, sizeof(unsigned long long)));
+	HIP_TRY(hipEventCreate(&c->evStart));
+	HIP_TRY(hipEventCreate(&c->evStop));
 	*out = c;
 	return PT_OK;
 }
@@ -262,6 +265,7 @@ extern "C" int pt_ctx_destroy(pt_ctx *c) {
 	(void)hipStreamSynchronize(c->stream);
 	(void)hipFree(c->image); (void)hipFree(c->geom); (void)hipFree(c->matA); (void)hipFree(c->matB);
 	(void)hipFree(c->seedmul); (void)hipFree(c->counter); (void)hipFree(c->u8);
+	(void)hipEventDestroy(c->evStart); (void)hipEventDestroy(c->evStop);
 	(void)hipStreamDestroy(c->stream);
 	free(c);
 	return PT_OK;
@@ -385,8 +389,15 @@ extern "C" int pt_render(pt_ctx *c, const pt_render_args *a) {
 		*a->bounce_count = (uint64_t)v;
 		return PT_OK;
 	}
+	if(a->kernel_ms) HIP_TRY(hipEventRecord(c->evStart, st));
 	hipLaunchKernelGGL(pt_render_kernel<false>, grid, block, 0, st, img, p, sc, c->seedmul, c->counter);
 	HIP_TRY(hipGetLastError());
+	if(a->kernel_ms) {
+		HIP_TRY(hipEventRecord(c->evStop, st));
+		HIP_TRY(hipEventSynchronize(c->evStop));
+		HIP_TRY(hipEventElapsedTime(a->kernel_ms, c->evStart, c->evStop));
+		return PT_OK;
+	}
 	if(!a->async) HIP_TRY(hipStreamSynchronize(st));
 	return PT_OK;
 }

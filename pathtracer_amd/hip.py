@@ -31,6 +31,7 @@ class RenderArgs(C.Structure):
         ("d_image", C.c_void_p), ("stream", C.c_void_p),
         ("bounce_count", C.POINTER(C.c_uint64)),
         ("async_", C.c_int),
+        ("kernel_ms", C.POINTER(C.c_float)),
     ]
 
 
@@ -109,9 +110,10 @@ class Context:
         _check(self.lib.pt_scene_upload(self.h, sp.ctypes.data_as(C.POINTER(C.c_float)), sp.shape[0]), "pt_scene_upload")
 
     def render(self, scene, width, height, max_depth, seeds, first_frame=0, rank=0, world=1, band_rows=16,
-               d_image=None, stream=None, count_bounces=False, async_=False):
+               d_image=None, stream=None, count_bounces=False, async_=False, time_kernel=False):
         """scene: dict with 'bg' and 'cam' (pathtracer_amd.scenes layout); the spheres must have
-        been uploaded with scene_upload().  Returns the bounce count if asked, else None."""
+        been uploaded with scene_upload().  Returns the bounce count (count_bounces) or the
+        HIP-event kernel time in ms (time_kernel) if asked, else None."""
         seeds = np.ascontiguousarray(seeds, np.uint64)
         a = RenderArgs()
         a.width, a.height, a.max_depth = width, height, max_depth
@@ -129,7 +131,11 @@ class Context:
         bc = C.c_uint64(0)
         a.bounce_count = C.pointer(bc) if count_bounces else None
         a.async_ = 1 if async_ else 0
+        ms = C.c_float(0)
+        a.kernel_ms = C.pointer(ms) if time_kernel else None
         _check(self.lib.pt_render(self.h, C.byref(a)), "pt_render")
+        if time_kernel:
+            return float(ms.value)
         return int(bc.value) if count_bounces else None
 
     def sync(self):
