@@ -120,22 +120,24 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    if args.steps > 256:
+        raise SystemExit("bench.py: at most 256 timed steps (size of the C ABI's kernel-timing ring)")
     barrier()
     t0 = time.perf_counter()
     for k in range(args.steps):
         if world > 1:
             frame.zero_()
-        ev[k][0].record()
+        # record_timing: the C ABI brackets the kernel with HIP events on the launch stream, no host sync
         ctx.render(scene, WIDTH, HEIGHT, DEPTH, seeds, rank=rank, world=world, band_rows=BAND_ROWS,
-                   d_image=frame.data_ptr(), stream=stream, async_=True)
-        ev[k][1].record()
+                   d_image=frame.data_ptr(), stream=stream, async_=True, record_timing=True)
         if world > 1:
             dist.reduce(frame, dst=0, op=dist.ReduceOp.SUM)
     barrier()
     dt = time.perf_counter() - t0
 
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    kern_times = ctx.kernel_times()
+    assert len(kern_times) == args.steps, (len(kern_times), args.steps)
+    kern_ms = float(np.mean(kern_times))
     tb = torch.tensor([float(my_bounces), dt, kern_ms], dtype=torch.float64, device=dev)
     if world > 1:
         tsum = tb.clone()
@@ -169,8 +171,12 @@ def main():
                        "partition": "1 GPU" if world == 1 else "%d-row bands round-robin over %d ranks + RCCL reduce" % (BAND_ROWS, world),
                        "bounces_per_sample": round(bps, 3)},
             "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_VALU_TFLOPS, "traffic": None,
-                         "kernel": "pt_render_kernel", "kernel_ms": kern_ms,
+                         "frac": achieved / PEAK_FP32_VALU_TFLOPS,
+                         # HBM bytes per launch from the PMC passes in profiles/ (WRITE_SIZE = the 16 B/pixel
+                         # accumulator written once, FETCH_SIZE ~0.1 MB): traffic == algorithmic bytes, and at
+                         # ~0.15 TB/s it is two orders of magnitude under the HBM roof — this path is VALU-bound
+                         "traffic": 16.0 * WIDTH * HEIGHT / max(world, 1) + 2 * 64e3 if world >= 1 else None,
+                         "kernel": "pt_render_lds_kernel", "kernel_ms": kern_ms,
                          "flops_per_sample": round(fps, 1),
                          "note": "FP32 vector roofline (no dense contraction on this path, SURVEY.md §8d); "
                                  "algorithmic FLOPs = B*(18N+34+30)+60 per sample with B measured in-kernel"},

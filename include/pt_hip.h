@@ -64,6 +64,9 @@ typedef struct pt_render_args {
 	float *kernel_ms;         /* optional HOST out: duration of the render kernel in ms, from HIP events
 	                             recorded on the launch stream around the launch.  Forces a
 	                             synchronisation.  NULL: not timed. */
+	int record_timing;        /* 1: bracket the render kernel with a pair of HIP events on the launch stream
+	                             WITHOUT synchronising; collect the durations later with pt_kernel_times().
+	                             At most 256 launches between two collections.  Ignored when kernel_ms is set. */
 } pt_render_args;
 
 /* Text of the last error on this thread ("" if none). */
@@ -93,6 +96,12 @@ int pt_scene_upload(pt_ctx *ctx, const float *spheres, int n);
  * clSetKernelArg ×7 + clEnqueueNDRangeKernel + clFinish (src/c/renderer.c:159-179,251). */
 int pt_render(pt_ctx *ctx, const pt_render_args *args);
 
+/* Durations (ms) of the render kernels launched with record_timing since the last call, oldest first:
+ * waits for those launches, writes up to `cap` values to ms[], stores the count in *n and empties the
+ * ring.  No reference counterpart (the reference times with gettimeofday around its loop,
+ * src/c/renderer.c:166,254-261); bench.py uses it for the per-launch kernel time of the roofline figure. */
+int pt_kernel_times(pt_ctx *ctx, float *ms, int cap, int *n);
+
 /* Block until everything enqueued on the context's stream has finished (clFinish, src/c/renderer.c:273). */
 int pt_sync(pt_ctx *ctx);
 
@@ -111,7 +120,10 @@ int pt_image_read_u8(pt_ctx *ctx, const void *d_image, int width, int height, un
  *   op 0: init_rng_2(a[i], b[i])                 -> out_u64[i]                (src/cl/rng.cl:7-9)
  *   op 1: state a[i]: rand_float                  -> out_u64[i]=state, out_f[i] (src/cl/rng.cl:11-14)
  *   op 2: state a[i]: random_unit_vector          -> out_u64[i]=state, out_f[3i..] (src/cl/rng.cl:20-34)
- *   op 3: in_f[2i]=x, in_f[2i+1]=y: x/y, sqrt(x), reflectance(x,y), pow5(x) -> out_f[4i..] */
+ *   op 3: in_f[2i]=x, in_f[2i+1]=y: x/y, sqrt(x), reflectance(x,y), pow5(x) -> out_f[4i..]
+ *   op 4: float bit patterns a[i] .. a[i]+b[i]-1: out_u64[i] = (#patterns where the kernels' short
+ *         correctly-rounded sqrt differs from sqrtf inside its stated domain) << 32
+ *         | #patterns where their guarded sqrt differs from sqrtf anywhere */
 int pt_selftest(pt_ctx *ctx, int op, const uint64_t *a, const uint64_t *b, const float *in_f,
                 int n, uint64_t *out_u64, float *out_f);
 

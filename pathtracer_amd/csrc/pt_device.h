@@ -22,7 +22,34 @@ PT_DEV f3 mul3(f3 a, f3 b) { return mk3(a.x * b.x, a.y * b.y, a.z * b.z); }
 PT_DEV f3 scl3(f3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
 // OpenCL dot/length/normalize as pinned in oracle/ref_shim.cpp
 PT_DEV float dot3(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
-PT_DEV float len3(f3 a) { return sqrtf(dot3(a, a)); }
+
+// Correctly rounded sqrt without the small-input rescaling of the compiler's expansion: v_sqrt_f32
+// (1 ulp) then the two neighbours are tried with an exact FMA residual.  Identical to sqrtf() for
+// x == +-0, every |x| >= 2^-96 (negative: NaN), +inf and NaN — pt_selftest op 4 checks every such
+// bit pattern on the device.  For 0 < |x| < 2^-96 it is not: the residual may underflow and
+// v_sqrt_f32 flushes denormal inputs (a negative denormal gives -0, not NaN).  Callers either know x
+// cannot be there or use sqrt_cr() below.  8 instead of 15 VALU operations after v_sqrt_f32.
+constexpr uint32_t PT_SQRT_TINY_BITS = 0x0f800000u;   // 2^-96
+PT_DEV float sqrt_nt(float x) {
+	float s = __builtin_amdgcn_sqrtf(x);
+	float sm = __uint_as_float(__float_as_uint(s) - 1u);
+	float sp = __uint_as_float(__float_as_uint(s) + 1u);
+	float rm = __builtin_fmaf(-sm, s, x);
+	float rp = __builtin_fmaf(-sp, s, x);
+	s = rm <= 0.0f ? sm : s;
+	s = rp > 0.0f ? sp : s;
+	return s;
+}
+
+// sqrtf() for every input: the short form where it is exact, the compiler's full expansion in the
+// (practically never taken) branch for 0 < x < 2^-96.
+PT_DEV float sqrt_cr(float x) {
+	float s = sqrt_nt(x);
+	if(__builtin_expect((__float_as_uint(x) & 0x7fffffffu) - 1u < PT_SQRT_TINY_BITS - 1u, 0)) s = sqrtf(x);
+	return s;
+}
+
+PT_DEV float len3(f3 a) { return sqrt_cr(dot3(a, a)); }
 PT_DEV f3 norm3(f3 a) { float inv = 1.0f / len3(a); return scl3(a, inv); }
 
 constexpr uint32_t PT_M31 = 2147483647u;   // MINSTD modulus 2^31 - 1 (src/cl/rng.cl:12)
@@ -63,8 +90,9 @@ PT_DEV float rand_pm1(uint32_t &state) { return -1.0f + rand_float(state) * 2.0f
 PT_DEV f3 random_unit_vector(uint32_t &state) {
 	float cosTheta = rand_pm1(state);
 	float cosPhi = rand_pm1(state);
-	float sinTheta = sqrtf(1.0f - cosTheta * cosTheta);
-	float sinPhi = sqrtf(1.0f - cosPhi * cosPhi);
+	// 1 - c*c with |c| <= 1 is 0 or >= 2^-24 (c*c is a float below 1 or exactly 1): sqrt_nt is exact
+	float sinTheta = sqrt_nt(1.0f - cosTheta * cosTheta);
+	float sinPhi = sqrt_nt(1.0f - cosPhi * cosPhi);
 	return mk3(sinTheta * cosPhi, sinTheta * sinPhi, cosTheta);
 }
 
@@ -92,6 +120,6 @@ PT_DEV f3 refraction_dir(f3 in, f3 n, float rel) {
 	float cosTheta = fminf(dot3(scl3(in, -1.0f), n), 1.0f);
 	f3 perp = scl3(add3(in, scl3(n, cosTheta)), rel);
 	float lp = len3(perp);
-	f3 par = scl3(n, -sqrtf(fabsf(1.0f - lp * lp)));
+	f3 par = scl3(n, -sqrt_cr(fabsf(1.0f - lp * lp)));
 	return add3(par, perp);
 }

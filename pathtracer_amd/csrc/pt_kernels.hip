@@ -24,6 +24,9 @@
 // Kernel parameters (by value: land in SGPRs — the reference passes its three structs by
 // value too, src/c/renderer.c:160-162)
 // ---------------------------------------------------------------------------------------
+#define PT_TIMING_SLOTS 256
+#define PT_LDS_MAX_SPHERES 512   // 24 KB of LDS per 256-thread block: 6 blocks = 24 waves per CU still fit
+
 struct KParams {
 	int W, H, maxDepth, n;
 	float bgx, bgy, bgz;
@@ -157,6 +160,177 @@ __global__ __launch_bounds__(256) void pt_render_kernel(float4 *__restrict__ ima
 }
 
 // ---------------------------------------------------------------------------------------
+// Closest hit (src/cl/ray.cl:101-110 with hit_sphere, :71-87)
+// ---------------------------------------------------------------------------------------
+struct Hit { bool hit; float t; int idx; };
+
+// The reference scan, as written: sqrt and divide per candidate, strict `<` on the rounded distances.
+template <typename Tab>
+PT_DEV Hit closest_hit_reference(const Tab geom, int n, f3 o, f3 d, float a) {
+	Hit h; h.hit = false; h.t = 0.0f; h.idx = 0;
+	for(int i = 0; i < n; i++) {
+		const float4 g = geom[i];
+		const f3 oc = sub3(o, mk3(g.x, g.y, g.z));
+		const float bHalf = dot3(oc, d);
+		const float c = oc.x * oc.x + oc.y * oc.y + oc.z * oc.z - g.w;
+		const float disc = bHalf * bHalf - a * c;
+		if(!(disc < 0.0f)) {
+			const float t = (-bHalf - sqrtf(disc)) / a;
+			if(t > 0.0f && (!h.hit || t < h.t)) { h.hit = true; h.t = t; h.idx = i; }
+		}
+	}
+	return h;
+}
+
+// Branch-free scan with ONE divide per ray instead of one per candidate.  Same result as
+// closest_hit_reference for every input; the argument:
+//  * num_i = -bHalf_i - sqrt(disc_i) is computed exactly as the reference does (sqrt_nt == sqrtf
+//    unless |disc| < 2^-96; the scan keeps min |disc| and raises `slow` below that, which also sends
+//    an exactly zero disc there — harmless).  A negative or NaN disc gives a NaN num.
+//  * With 2^-40 <= a <= 2^40 and 2^-80 <= num <= 2^80 the quotient t = num/a neither underflows nor
+//    overflows, so t > 0 <=> num > 0, and rounding is monotonic: num_i < num_j => t_i <= t_j.
+//    A NaN or non-positive num is no hit on both sides.  Outside those ranges: `slow`.
+//  * Positive floats order like their bit patterns, so key = bits(num) - 1 (wrapping) puts every
+//    valid num below KEY_NONE and everything else (+0 -> 0xffffffff, negatives, NaNs, +inf) at or
+//    above it.  The scan keeps the smallest key with the lowest index (strict <), and `prev`, the
+//    smallest key among LOWER indices (the running minimum just before the last update).
+//  * The reference's winner is the lowest index among the spheres whose ROUNDED t is minimal.  That
+//    is our index unless a lower-indexed sphere with a larger num rounds to the same t; by
+//    monotonicity the smallest such num is `prev`, and if prev > num * (1 + 2^-21) the two quotients
+//    are more than an ulp apart.  Otherwise: `slow`.
+//  `slow` lanes re-run the reference scan (whole wave skips it when no lane asks).
+constexpr uint32_t KEY_NONE = 0x7f7fffffu;   // bits(+inf) - 1
+
+PT_DEV void test_sphere(const float4 g, int i, f3 o, f3 d, float a, uint32_t &best, uint32_t &prev, int &idx, float &tiny) {
+	const f3 oc = sub3(o, mk3(g.x, g.y, g.z));
+	const float bHalf = dot3(oc, d);
+	const float c = oc.x * oc.x + oc.y * oc.y + oc.z * oc.z - g.w;
+	const float disc = bHalf * bHalf - a * c;
+	tiny = fminf(tiny, fabsf(disc));      // a NaN disc is ignored by fminf, and is no hit on either path
+	const float num = -bHalf - sqrt_nt(disc);
+	const uint32_t key = __float_as_uint(num) - 1u;
+	const bool upd = key < best;
+	prev = upd ? best : prev;
+	idx = upd ? i : idx;
+	best = upd ? key : best;
+}
+
+template <typename Tab>
+PT_DEV Hit closest_hit(const Tab geom, int n, f3 o, f3 d, float a) {
+	uint32_t best = KEY_NONE, prev = KEY_NONE;
+	float tiny = __builtin_inff();
+	int idx = 0;
+	int i = 0;
+	for(; i + 3 <= n; i += 3) {
+		const float4 g0 = geom[i], g1 = geom[i + 1], g2 = geom[i + 2];
+		test_sphere(g0, i, o, d, a, best, prev, idx, tiny);
+		test_sphere(g1, i + 1, o, d, a, best, prev, idx, tiny);
+		test_sphere(g2, i + 2, o, d, a, best, prev, idx, tiny);
+	}
+	for(; i < n; i++) test_sphere(geom[i], i, o, d, a, best, prev, idx, tiny);
+	Hit h;
+	h.hit = best < KEY_NONE;
+	h.idx = idx;
+	const float num = __uint_as_float(best + 1u);
+	const float pnum = __uint_as_float(prev + 1u);           // +inf when there is none
+	h.t = num / a;
+	bool slow = tiny < 0x1p-96f;
+	slow |= !(a >= 0x1p-40f && a <= 0x1p40f);
+	slow |= h.hit && (!(num >= 0x1p-80f && num <= 0x1p80f) || pnum <= num * (1.0f + 0x1p-21f));
+	if(__builtin_expect(slow, 0)) h = closest_hit_reference(geom, n, o, d, a);
+	return h;
+}
+
+// ---------------------------------------------------------------------------------------
+// Kernel v2 (scenes whose tables fit in LDS): one thread per pixel, all samples in-kernel,
+// lock-step sample loop, geometry and material tables staged in LDS and read back as
+// wave-uniform (geometry) or per-lane (material of the winning sphere) ds_reads, so the
+// arithmetic runs on VGPR operands at full VALU rate.
+// ---------------------------------------------------------------------------------------
+template <bool COUNT>
+__global__ __launch_bounds__(256) void pt_render_lds_kernel(float4 *__restrict__ image, const KParams p, const SceneTables sc,
+                                                             const uint64_t *__restrict__ seedmul,
+                                                             unsigned long long *__restrict__ bounceCounter) {
+	extern __shared__ float4 lds[];
+	float4 *const sGeom = lds, *const sMatA = lds + p.n, *const sMatB = lds + 2 * p.n;
+	for(int i = (int)threadIdx.x; i < p.n; i += (int)blockDim.x) {
+		sGeom[i] = sc.geom[i];
+		sMatA[i] = sc.matA[i];
+		sMatB[i] = sc.matB[i];
+	}
+	__syncthreads();
+	const int id = pixel_id(p, (int)(blockIdx.x * blockDim.x + threadIdx.x));
+	unsigned int myBounces = 0;
+	if(id >= 0) {
+		const f3 pos = mk3(p.px, p.py, p.pz);
+		const f3 origin = camera_origin(p, id);
+		f3 acc = mk3(0.0f, 0.0f, 0.0f);
+		if(p.firstFrame > 0) {
+			float4 v = image[id];
+			acc = mk3(v.x, v.y, v.z);
+		}
+		for(int k = 0; k < p.nFrames; k++) {
+			uint32_t rng = init_rng_2((uint32_t)id, seedmul[k]);                       // main.cl:6
+			f3 target = add3(pos, scl3(random_unit_vector(rng), p.aperture));            // main.cl:19
+			f3 d = norm3(sub3(target, origin));                                          // main.cl:21
+			f3 o = pos;                                                                  // main.cl:23
+			f3 color = mk3(0.0f, 0.0f, 0.0f), mask = mk3(1.0f, 1.0f, 1.0f);              // ray.cl:92-93
+			for(int j = 0; j < p.maxDepth; j++) {                                        // ray.cl:96
+				if(COUNT) myBounces++;
+				const float ln = len3(d);
+				const float a = ln * ln;                                                 // ray.cl:73 pow(length(d),2)
+				const Hit h = closest_hit(sGeom, p.n, o, d, a);
+				if(!h.hit) { color = mul3(mask, mk3(p.bgx, p.bgy, p.bgz)); break; }      // ray.cl:112-115
+				const float4 g = sGeom[h.idx];
+				const float4 mA = sMatA[h.idx];
+				const float4 mB = sMatB[h.idx];
+				const int type = __float_as_int(mA.w);
+				const f3 mcol = mk3(mA.x, mA.y, mA.z);
+				const f3 hitPos = add3(o, scl3(d, h.t));                                 // ray.cl:117
+				f3 normal = norm3(sub3(hitPos, mk3(g.x, g.y, g.z)));                     // ray.cl:118
+				const f3 offPos = sub3(hitPos, scl3(normal, 0.0001f));                   // ray.cl:119
+				bool front = true;
+				if(dot3(d, normal) > 0.0f) { front = false; normal = scl3(normal, -1.0f); }   // ray.cl:122-128
+				if(type == 0) {                                                          // ray.cl:130-134
+					if(front) { color = mul3(mask, mcol); break; }
+				} else if(type == 1) {                                                   // ray.cl:136-141
+					if(front) {
+						d = add3(normal, random_unit_vector(rng));
+						o = offPos;
+						mask = mul3(mask, mcol);
+					}
+				} else if(type == 2) {                                                   // ray.cl:143-148
+					if(front) {
+						d = add3(reflection_dir(d, normal), scl3(random_unit_vector(rng), mB.y));
+						o = offPos;
+						mask = add3(scl3(mask, 1.0f - mB.x), scl3(mul3(mask, mcol), mB.x));
+					}
+				} else if(type == 3) {                                                   // ray.cl:150-171
+					const float rel = front ? mB.z : 1.0f / mB.z;
+					const float cosTheta = fminf(dot3(scl3(d, -1.0f), normal), 1.0f);
+					const float sinTheta = sqrt_cr(1.0f - cosTheta * cosTheta);
+					bool reflect = rel * sinTheta > 1.0f;
+					if(!reflect) reflect = reflectance(cosTheta, rel) > rand_float(rng);    // short-circuit draw, ray.cl:163
+					const f3 base = reflect ? reflection_dir(d, normal) : refraction_dir(d, normal, rel);
+					d = add3(base, scl3(random_unit_vector(rng), mB.y));
+					o = offPos;
+					mask = add3(scl3(mask, 1.0f - mB.x), scl3(mul3(mask, mcol), mB.x));
+				}
+			}
+			color = scl3(scl3(color, p.exposure), p.aperture);                           // main.cl:27
+			const float f = (float)(p.firstFrame + k), f1 = (float)(p.firstFrame + k + 1);
+			acc = mk3((acc.x * f + color.x) / f1, (acc.y * f + color.y) / f1, (acc.z * f + color.z) / f1);   // main.cl:29
+		}
+		image[id] = make_float4(acc.x, acc.y, acc.z, 0.0f);
+	}
+	if(COUNT) {
+		unsigned int v = myBounces;
+		for(int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+		if((threadIdx.x & 63) == 0 && v) atomicAdd(bounceCounter, (unsigned long long)v);
+	}
+}
+
+// ---------------------------------------------------------------------------------------
 // Epilogue: gamma (sqrt), clamp, (int)(x*255) truncation -> packed RGB8
 // (src/c/renderer.c:50-56, 17-39).  sqrtf == (float)sqrt((double)x) for every float.
 // ---------------------------------------------------------------------------------------
@@ -197,6 +371,21 @@ __global__ void pt_selftest_kernel(int op, const uint64_t *a, const uint64_t *b,
 		of[4 * i + 1] = sqrtf(x);
 		of[4 * i + 2] = reflectance(x, y);
 		of[4 * i + 3] = pow5(x);
+	} else if(op == 4) {
+		// bit patterns a[i] .. a[i] + b[i] - 1: how many have sqrt_cr != sqrtf, how many in sqrt_nt's
+		// stated domain (0, >= 2^-96, inf, NaN, negative) have sqrt_nt != sqrtf (NaN == NaN here)
+		uint64_t bad_cr = 0, bad_nt = 0;
+		for(uint64_t k = 0; k < b[i]; k++) {
+			const uint32_t u = (uint32_t)(a[i] + k);
+			const float x = __uint_as_float(u);
+			const float want = sqrtf(x);
+			const float g1 = sqrt_cr(x), g2 = sqrt_nt(x);
+			const bool nanw = want != want;
+			if(nanw ? (g1 == g1) : (__float_as_uint(g1) != __float_as_uint(want))) bad_cr++;
+			const bool dom = !((u & 0x7fffffffu) - 1u < PT_SQRT_TINY_BITS - 1u);
+			if(dom && (nanw ? (g2 == g2) : (__float_as_uint(g2) != __float_as_uint(want)))) bad_nt++;
+		}
+		ou[i] = bad_cr + (bad_nt << 32);
 	}
 }
 
@@ -225,9 +414,12 @@ struct pt_ctx {
 	float4 *image; int imgW, imgH;
 	float4 *geom, *matA, *matB; int nSpheres, capSpheres;
 	uint64_t *seedmul; int capSeeds;
+	uint64_t *hostSeedmul; int nHostSeeds;   // what seedmul holds, to skip identical re-uploads
 	unsigned long long *counter;
 	unsigned char *u8; size_t capU8;
 	hipEvent_t evStart, evStop;
+	hipEvent_t ring[2 * PT_TIMING_SLOTS];   // start/stop pairs of launches made with record_timing
+	int nTimed;
 };
 
 extern "C" const char *pt_last_error(void) { return g_err; }
@@ -255,6 +447,7 @@ extern "C" int pt_ctx_create(int device, pt_ctx **out) {
 	HIP_TRY(hipMalloc((void **)&c->counter, sizeof(unsigned long long)));
 	HIP_TRY(hipEventCreate(&c->evStart));
 	HIP_TRY(hipEventCreate(&c->evStop));
+	for(int i = 0; i < 2 * PT_TIMING_SLOTS; i++) HIP_TRY(hipEventCreate(&c->ring[i]));
 	*out = c;
 	return PT_OK;
 }
@@ -266,7 +459,9 @@ extern "C" int pt_ctx_destroy(pt_ctx *c) {
 	(void)hipFree(c->image); (void)hipFree(c->geom); (void)hipFree(c->matA); (void)hipFree(c->matB);
 	(void)hipFree(c->seedmul); (void)hipFree(c->counter); (void)hipFree(c->u8);
 	(void)hipEventDestroy(c->evStart); (void)hipEventDestroy(c->evStop);
+	for(int i = 0; i < 2 * PT_TIMING_SLOTS; i++) (void)hipEventDestroy(c->ring[i]);
 	(void)hipStreamDestroy(c->stream);
+	free(c->hostSeedmul);
 	free(c);
 	return PT_OK;
 }
@@ -354,14 +549,23 @@ extern "C" int pt_render(pt_ctx *c, const pt_render_args *a) {
 		int cap = a->n_frames < 256 ? 256 : a->n_frames;
 		HIP_TRY(hipMalloc((void **)&c->seedmul, sizeof(uint64_t) * (size_t)cap));
 		c->capSeeds = cap;
+		free(c->hostSeedmul); c->hostSeedmul = NULL; c->nHostSeeds = 0;
 	}
 	uint64_t *hs = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)a->n_frames);
 	if(!hs) return fail(PT_E_NOMEM, "pt_render: host allocation failed%s", NULL);
 	for(int k = 0; k < a->n_frames; k++) hs[k] = 16807ull * a->seeds[k];     // src/cl/rng.cl:8, folded per sample
-	hipError_t ec = hipMemcpyAsync(c->seedmul, hs, sizeof(uint64_t) * (size_t)a->n_frames, hipMemcpyHostToDevice, st);
-	hipError_t es = hipStreamSynchronize(st);   // pageable staging buffer: finish the copy before freeing it
-	free(hs);
-	HIP_TRY(ec); HIP_TRY(es);
+	if(c->hostSeedmul && c->nHostSeeds == a->n_frames && memcmp(hs, c->hostSeedmul, sizeof(uint64_t) * (size_t)a->n_frames) == 0) {
+		free(hs);   // the device table already holds these seeds: nothing to copy, no host synchronisation
+	} else {
+		// the table may still be read by an earlier launch on another stream: drain the context first
+		hipError_t e0 = hipStreamSynchronize(c->stream);
+		hipError_t e1 = st != c->stream ? hipStreamSynchronize(st) : hipSuccess;
+		hipError_t ec = hipMemcpyAsync(c->seedmul, hs, sizeof(uint64_t) * (size_t)a->n_frames, hipMemcpyHostToDevice, st);
+		hipError_t es = hipStreamSynchronize(st);   // pageable staging buffer: finish the copy before reusing it
+		free(c->hostSeedmul);
+		c->hostSeedmul = hs; c->nHostSeeds = a->n_frames;
+		HIP_TRY(e0); HIP_TRY(e1); HIP_TRY(ec); HIP_TRY(es);
+	}
 
 	KParams p;
 	p.W = a->width; p.H = a->height; p.maxDepth = a->max_depth; p.n = c->nSpheres;
@@ -379,9 +583,13 @@ extern "C" int pt_render(pt_ctx *c, const pt_render_args *a) {
 
 	SceneTables sc = {c->geom, c->matA, c->matB};
 	dim3 block(256), grid((unsigned)((lp + 255) / 256));
+	// tables of up to PT_LDS_MAX_SPHERES spheres (48 B each) are staged whole in LDS
+	const bool useLds = c->nSpheres <= PT_LDS_MAX_SPHERES && !getenv("PT_FORCE_V1");
+	const size_t ldsBytes = useLds ? 3 * sizeof(float4) * (size_t)c->nSpheres : 0;
 	if(a->bounce_count) {
 		HIP_TRY(hipMemsetAsync(c->counter, 0, sizeof(unsigned long long), st));
-		hipLaunchKernelGGL(pt_render_kernel<true>, grid, block, 0, st, img, p, sc, c->seedmul, c->counter);
+		if(useLds) hipLaunchKernelGGL(pt_render_lds_kernel<true>, grid, block, ldsBytes, st, img, p, sc, c->seedmul, c->counter);
+		else hipLaunchKernelGGL(pt_render_kernel<true>, grid, block, 0, st, img, p, sc, c->seedmul, c->counter);
 		HIP_TRY(hipGetLastError());
 		unsigned long long v = 0;
 		HIP_TRY(hipMemcpyAsync(&v, c->counter, sizeof v, hipMemcpyDeviceToHost, st));
@@ -389,9 +597,15 @@ extern "C" int pt_render(pt_ctx *c, const pt_render_args *a) {
 		*a->bounce_count = (uint64_t)v;
 		return PT_OK;
 	}
+	const bool ringTimed = a->record_timing && !a->kernel_ms;
+	if(ringTimed && c->nTimed >= PT_TIMING_SLOTS)
+		return fail(PT_E_STATE, "pt_render: timing ring full (call pt_kernel_times)%s", NULL);
 	if(a->kernel_ms) HIP_TRY(hipEventRecord(c->evStart, st));
-	hipLaunchKernelGGL(pt_render_kernel<false>, grid, block, 0, st, img, p, sc, c->seedmul, c->counter);
+	if(ringTimed) HIP_TRY(hipEventRecord(c->ring[2 * c->nTimed], st));
+	if(useLds) hipLaunchKernelGGL(pt_render_lds_kernel<false>, grid, block, ldsBytes, st, img, p, sc, c->seedmul, c->counter);
+	else hipLaunchKernelGGL(pt_render_kernel<false>, grid, block, 0, st, img, p, sc, c->seedmul, c->counter);
 	HIP_TRY(hipGetLastError());
+	if(ringTimed) { HIP_TRY(hipEventRecord(c->ring[2 * c->nTimed + 1], st)); c->nTimed++; }
 	if(a->kernel_ms) {
 		HIP_TRY(hipEventRecord(c->evStop, st));
 		HIP_TRY(hipEventSynchronize(c->evStop));
@@ -399,6 +613,19 @@ extern "C" int pt_render(pt_ctx *c, const pt_render_args *a) {
 		return PT_OK;
 	}
 	if(!a->async) HIP_TRY(hipStreamSynchronize(st));
+	return PT_OK;
+}
+
+extern "C" int pt_kernel_times(pt_ctx *c, float *ms, int cap, int *n) {
+	if(!c || !n || (cap > 0 && !ms)) return fail(PT_E_INVALID, "pt_kernel_times: NULL%s", NULL);
+	HIP_TRY(hipSetDevice(c->device));
+	int k = 0;
+	for(; k < c->nTimed && k < cap; k++) {
+		HIP_TRY(hipEventSynchronize(c->ring[2 * k + 1]));
+		HIP_TRY(hipEventElapsedTime(&ms[k], c->ring[2 * k], c->ring[2 * k + 1]));
+	}
+	*n = k;
+	c->nTimed = 0;
 	return PT_OK;
 }
 
@@ -442,7 +669,7 @@ extern "C" int pt_image_read_u8(pt_ctx *c, const void *d_image, int width, int h
 
 extern "C" int pt_selftest(pt_ctx *c, int op, const uint64_t *a, const uint64_t *b, const float *in_f, int n,
                            uint64_t *out_u64, float *out_f) {
-	if(!c || n <= 0 || op < 0 || op > 3) return fail(PT_E_INVALID, "pt_selftest: bad arguments%s", NULL);
+	if(!c || n <= 0 || op < 0 || op > 4) return fail(PT_E_INVALID, "pt_selftest: bad arguments%s", NULL);
 	HIP_TRY(hipSetDevice(c->device));
 	uint64_t *da = NULL, *db = NULL, *dou = NULL;
 	float *dif = NULL, *dof = NULL;

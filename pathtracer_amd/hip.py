@@ -32,6 +32,7 @@ class RenderArgs(C.Structure):
         ("bounce_count", C.POINTER(C.c_uint64)),
         ("async_", C.c_int),
         ("kernel_ms", C.POINTER(C.c_float)),
+        ("record_timing", C.c_int),
     ]
 
 
@@ -39,7 +40,7 @@ _lib = None
 
 # every symbol include/pt_hip.h declares
 EXPORTS = ["pt_last_error", "pt_device_count", "pt_ctx_create", "pt_ctx_destroy", "pt_image_alloc",
-           "pt_scene_upload", "pt_render", "pt_sync", "pt_image_read", "pt_image_read_u8", "pt_selftest"]
+           "pt_scene_upload", "pt_render", "pt_kernel_times", "pt_sync", "pt_image_read", "pt_image_read_u8", "pt_selftest"]
 
 
 def load():
@@ -57,6 +58,7 @@ def load():
     lib.pt_image_alloc.argtypes = [C.c_void_p, C.c_int, C.c_int]
     lib.pt_scene_upload.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_int]
     lib.pt_render.argtypes = [C.c_void_p, C.POINTER(RenderArgs)]
+    lib.pt_kernel_times.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_int)]
     lib.pt_sync.argtypes = [C.c_void_p]
     lib.pt_image_read.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
     lib.pt_image_read_u8.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_ubyte)]
@@ -110,7 +112,7 @@ class Context:
         _check(self.lib.pt_scene_upload(self.h, sp.ctypes.data_as(C.POINTER(C.c_float)), sp.shape[0]), "pt_scene_upload")
 
     def render(self, scene, width, height, max_depth, seeds, first_frame=0, rank=0, world=1, band_rows=16,
-               d_image=None, stream=None, count_bounces=False, async_=False, time_kernel=False):
+               d_image=None, stream=None, count_bounces=False, async_=False, time_kernel=False, record_timing=False):
         """scene: dict with 'bg' and 'cam' (pathtracer_amd.scenes layout); the spheres must have
         been uploaded with scene_upload().  Returns the bounce count (count_bounces) or the
         HIP-event kernel time in ms (time_kernel) if asked, else None."""
@@ -133,10 +135,18 @@ class Context:
         a.async_ = 1 if async_ else 0
         ms = C.c_float(0)
         a.kernel_ms = C.pointer(ms) if time_kernel else None
+        a.record_timing = 1 if record_timing else 0
         _check(self.lib.pt_render(self.h, C.byref(a)), "pt_render")
         if time_kernel:
             return float(ms.value)
         return int(bc.value) if count_bounces else None
+
+    def kernel_times(self, cap=256):
+        """Durations (ms) of the launches made with record_timing=True since the last call."""
+        ms = (C.c_float * cap)()
+        n = C.c_int(0)
+        _check(self.lib.pt_kernel_times(self.h, ms, cap, C.byref(n)), "pt_kernel_times")
+        return [float(ms[i]) for i in range(n.value)]
 
     def sync(self):
         _check(self.lib.pt_sync(self.h), "pt_sync")

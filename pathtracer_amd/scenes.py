@@ -146,6 +146,28 @@ def material_micro(kind):
     return _pack(s, [0.6, 0.7, 0.9], cam)
 
 
+def degenerate():
+    """Ties and touching surfaces for the closest-hit scan: exact duplicates (the lowest index must
+    win, src/cl/ray.cl:104 strict <), concentric shells, tangent spheres, a zero-radius sphere, a sphere
+    around the camera (near root only: never hit from inside) and one far behind it."""
+    s = [
+        _sphere(0, -1001, -8, 1000, lambertian(0.7, 0.7, 0.7)),
+        _sphere(-1.5, 0, -8, 1, metal(0.9, 0.2, 0.2, 0.7, 0.1)),
+        _sphere(-1.5, 0, -8, 1, lambertian(0.2, 0.9, 0.2)),            # duplicate of the metal sphere
+        _sphere(1.5, 0, -8, 1, dielectric(0.9, 0.9, 1.0, 0.3, 0.0, 1.5)),
+        _sphere(1.5, 0, -8, 0.5, light_source(6, 5, 4)),               # concentric, inside the glass
+        _sphere(1.5, 0, -8, 1, light_source(1, 2, 3)),                 # duplicate of the glass shell
+        _sphere(0, 1.5, -8, 0.5, lambertian(0.3, 0.3, 0.9)),
+        _sphere(0, 2.5, -8, 0.5, metal(0.8, 0.8, 0.8, 0.5, 0.0)),      # tangent to the one below
+        _sphere(0, 0.5, -6, 0.0, light_source(9, 9, 9)),               # zero radius
+        _sphere(0, 0, 0, 3, lambertian(0.5, 0.1, 0.1)),                # camera inside
+        _sphere(0, 0, 40, 5, light_source(3, 3, 3)),                   # behind the camera
+        _sphere(0, -1001, -8, 1000, light_source(5, 5, 5)),            # duplicate of the floor
+    ]
+    cam = [0, 0.5, 0, 0.0, 0.0, 0.0, 6, 7, 0.02, 50]
+    return _pack(s, [0.4, 0.5, 0.7], cam)
+
+
 def empty():
     """No spheres: every path misses on its first bounce and returns the background."""
     cam = [0, 0, 0, 0, 0, 0, 15, 20, 0.001, 1000]

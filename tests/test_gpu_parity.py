@@ -69,6 +69,30 @@ def test_divide_sqrt_correctly_rounded(ctx, oracle):
     assert (bits(of[:20000, 2]) != bits(want)).sum() <= 1
 
 
+def test_short_sqrt_is_sqrtf_on_every_float(ctx):
+    """The kernels' short correctly-rounded sqrt (pt_device.h sqrt_nt / sqrt_cr) against the compiler's
+    correctly rounded sqrtf on ALL 2^32 bit patterns, on the device (sqrtf itself is pinned against the
+    CPU in test_divide_sqrt_correctly_rounded)."""
+    n = 1 << 16
+    a = (np.arange(n, dtype=np.uint64) << np.uint64(16))
+    b = np.full(n, 1 << 16, np.uint64)
+    ou, _ = ctx.selftest(4, a=a, b=b)
+    assert int((ou & np.uint64(0xFFFFFFFF)).sum()) == 0, "sqrt_cr != sqrtf somewhere"
+    assert int((ou >> np.uint64(32)).sum()) == 0, "sqrt_nt != sqrtf inside its domain"
+
+
+def test_kernel_timing_ring(ctx):
+    sc = scenes.main_lua_frame(0)
+    ctx.scene_upload(sc["spheres"])
+    ctx.image_alloc(64, 36)
+    s = seedmod.glibc_rand_stream(2)
+    for _ in range(3):
+        ctx.render(sc, 64, 36, 50, s, async_=True, record_timing=True)
+    t = ctx.kernel_times()
+    assert len(t) == 3 and all(0 < x < 1000 for x in t)
+    assert ctx.kernel_times() == []
+
+
 @pytest.mark.parametrize("name", sorted(CASES))
 def test_render_matches_oracle_and_reference_fixture(ctx, oracle, name):
     g = np.load(os.path.join(GOLD, name + ".npz"))

@@ -29,7 +29,10 @@ def main():
     os.makedirs(out, exist_ok=True)
     strict, fast = oracle_lib.load_ref("strict"), oracle_lib.load_ref("fast")
     stream = seedmod.glibc_rand_stream(64)
+    only = set(sys.argv[1:])     # optional: case names to (re)write; "kat" for the single-function vectors
     for name, (factory, W, H, depth, spp) in CASES.items():
+        if only and name not in only:
+            continue
         sc = factory()
         s = stream[:spp]
         a = strict.render(sc, W, H, depth, s)
@@ -40,6 +43,8 @@ def main():
         print("%-22s %dx%d depth %d spp %d  mean %.5f  |strict-fast|max %.3g" %
               (name, W, H, depth, spp, float(a[..., :3].mean()), float(np.abs(a - b).max())))
 
+    if only and "kat" not in only:
+        return
     # single-function KATs from the strict build
     rng = np.random.RandomState(7)
     kat = {}

@@ -1,0 +1,24 @@
+#!/bin/bash
+# rocprofv3 counter passes (one run per pass: <=8 SQ, <=4 TCC, <=2 GRBM counters each) over
+# tools/prof_run.py.  Usage: tools/pmc_passes.sh <tag> [prof_run args...]; CSVs land in gpurun_out/pmc_<tag>/.
+set -u
+tag=$1; shift
+root=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+out=$root/gpurun_out/pmc_$tag
+mkdir -p "$out"
+cd /tmp && export TMPDIR=/tmp
+passes=(
+ "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_WAIT_ANY GRBM_GUI_ACTIVE"
+ "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA SQ_THREAD_CYCLES_VALU SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32"
+ "SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_MUL_F64 SQ_INSTS_BRANCH SQ_INST_CYCLES_SALU SQ_INSTS_LDS SQ_INSTS_VMEM"
+ "FETCH_SIZE"
+ "WRITE_SIZE"
+)
+i=0
+for p in "${passes[@]}"; do
+  i=$((i+1))
+  echo "== pass $i: $p"
+  timeout -s KILL 120 rocprofv3 --pmc $p -d "$out/p$i" -o p$i --output-format csv -- python3 "$root/tools/prof_run.py" "$@" > "$out/p$i.log" 2>&1 || { echo "pass $i failed"; tail -5 "$out/p$i.log"; exit 1; }
+  tail -1 "$out/p$i.log"
+done
+find "$out" -name "*counter_collection.csv" | head
