@@ -36,7 +36,9 @@ def main():
               (g("SQ_INSTS_VALU") / g("SQ_WAVES"), g("SQ_INSTS_SALU", 0) / g("SQ_WAVES"), g("SQ_INSTS_SMEM", 0) / g("SQ_WAVES")))
     if g("SQ_THREAD_CYCLES_VALU") and g("SQ_ACTIVE_INST_VALU"):
         print("- mean active lanes per VALU instruction (divergence): %.1f of 64" %
-              (g("SQ_THREAD_CYCLES_VALU") / g("SQ_ACTIVE_INST_VALU") / 4.0 * 1.0))
+              (g("SQ_THREAD_CYCLES_VALU") / g("SQ_ACTIVE_INST_VALU")))
+    if g("GRBM_GUI_ACTIVE"):
+        print("- GRBM_GUI_ACTIVE / 8 XCDs = %.4g shader-clock cycles per dispatch" % (g("GRBM_GUI_ACTIVE") / 8))
     if g("FETCH_SIZE") is not None:
         print("- FETCH_SIZE %.4g KB per dispatch (x2 for wide coalesced reads on gfx950, MI355X_MICROARCH.md HBM section)" % g("FETCH_SIZE"))
     if g("WRITE_SIZE") is not None:
