@@ -28,6 +28,10 @@ def main():
     ctx = hip.Context(0)
     ctx.scene_upload(sc["spheres"])
     ctx.image_alloc(W, H)
+    if os.environ.get("PT_COUNT", "1") != "0":
+        cs = s[:min(spp, 2)]
+        bc = ctx.render(sc, W, H, depth, cs, count_bounces=True)
+        print("bounce iterations per sample: %.3f (over %d spp)" % (bc / (W * H * len(cs)), len(cs)), flush=True)
     for r in range(reps):
         t0 = time.perf_counter()
         ms = ctx.render(sc, W, H, depth, s, time_kernel=True)
