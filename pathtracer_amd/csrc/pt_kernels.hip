@@ -255,16 +255,17 @@ PT_DEV Hit closest_hit_reference(const Tab geom, int n, f3 o, f3 d, float a) {
 //  * With 2^-40 <= a <= 2^40 and 2^-80 <= num <= 2^80 the quotient t = num/a neither underflows nor
 //    overflows, so t > 0 <=> num > 0, and rounding is monotonic: num_i < num_j => t_i <= t_j.
 //    A NaN or non-positive num is no hit on both sides.  Outside those ranges: `slow`.
-//  * Positive floats order like their bit patterns, so key = bits(num) - 1 (wrapping) puts every
-//    valid num below KEY_NONE and everything else (+0 -> 0xffffffff, negatives, NaNs, +inf) at or
-//    above it.  The scan keeps the smallest key with the lowest index (strict <), and `prev`, the
+//  * Positive floats order like their bit patterns, so key = bits(num) puts every valid num below
+//    KEY_NONE = bits(+inf) and negatives, NaNs and +inf at or above it.  num == +0 (t == 0: no hit in
+//    the reference) is the one invalid value that sorts first; it then wins the scan, is seen at the
+//    end (best == 0) and raises `slow`.  The scan keeps the smallest key with the lowest index (strict <), and `prev`, the
 //    smallest key among LOWER indices (the running minimum just before the last update).
 //  * The reference's winner is the lowest index among the spheres whose ROUNDED t is minimal.  That
 //    is our index unless a lower-indexed sphere with a larger num rounds to the same t; by
 //    monotonicity the smallest such num is `prev`, and if prev > num * (1 + 2^-21) the two quotients
 //    are more than an ulp apart.  Otherwise: `slow`.
 //  `slow` lanes re-run the reference scan (whole wave skips it when no lane asks).
-constexpr uint32_t KEY_NONE = 0x7f7fffffu;   // bits(+inf) - 1
+constexpr uint32_t KEY_NONE = 0x7f800000u;   // bits(+inf)
 
 // src/cl/ray.cl:72-76 — bHalf and the discriminant, in the reference's operation order
 PT_DEV void sphere_disc(const float4 g, f3 o, f3 d, float a, float &bHalf, float &disc) {
@@ -277,7 +278,7 @@ PT_DEV void sphere_disc(const float4 g, f3 o, f3 d, float a, float &bHalf, float
 PT_DEV void candidate_update(float bHalf, float disc, int i, uint32_t &best, uint32_t &prev, int &idx, uint32_t &tiny) {
 	tiny = min(tiny, (__float_as_uint(disc) & 0x7fffffffu) - 1u);   // smallest non-zero |disc| seen (zero wraps to the top)
 	const float num = -bHalf - sqrt_nt(disc);
-	const uint32_t key = __float_as_uint(num) - 1u;
+	const uint32_t key = __float_as_uint(num);
 	const bool upd = key < best;
 	prev = upd ? best : prev;
 	idx = upd ? i : idx;
@@ -320,8 +321,8 @@ PT_DEV Hit finish_scan(float a, uint32_t best, uint32_t prev, int idx, uint32_t 
 	Hit h;
 	h.hit = best < KEY_NONE;
 	h.idx = idx;
-	const float num = __uint_as_float(best + 1u);
-	const float pnum = __uint_as_float(prev + 1u);           // +inf when there is none
+	const float num = __uint_as_float(best);
+	const float pnum = __uint_as_float(prev);                // +inf when there is none
 	h.t = num / a;
 	slow = tiny < PT_SQRT_TINY_BITS - 1u;
 	slow |= !(a >= 0x1p-40f && a <= 0x1p40f);
