@@ -8,6 +8,7 @@
  * pixel come back, and with PT_NUM_GPUS > 1 the image is cut into row bands over several GPUs.
  */
 #include <math.h>
+#include <pthread.h>
 #include <stdarg.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -28,9 +29,57 @@
 #define PT_MAX_GPUS 8
 #define PT_BAND_ROWS 8
 
+#define PT_MAX_PIPE 4
+#define PT_PIPE_DEPTH 2   /* frames queued per GPU before render_to_file() blocks */
+
+/* One render_to_file() call, detached from the Renderer: everything the frame needs is copied at
+ * call time (scene, camera, its seeds in stream order), so the caller may go on editing the scene. */
+typedef struct pt_job {
+	struct pt_job *next;
+	float *flat; int n;
+	uint64_t *seeds; int samples;
+	pt_render_args args;
+	char *fileName;
+} pt_job;
+
+struct pt_encpool;
+typedef struct pt_worker {
+	pthread_t thread;
+	pthread_mutex_t lock;
+	pthread_cond_t wake, room;
+	pt_job *head, *tail;
+	int pending;          /* queued + running */
+	int quit, started;
+	pt_ctx *ctx;
+	int imgW, imgH;
+	struct pt_encpool *enc;
+} pt_worker;
+
+/* encoder pool of the frame pipeline: PNG/JPG encoding is host work that outlasts the render of a
+ * small frame several times, so finished 8-bit images go to PT_ENCODERS threads */
+#define PT_ENCODERS 4
+#define PT_ENCODE_QUEUE 8
+typedef struct pt_encjob { struct pt_encjob *next; Image image; char *fileName; } pt_encjob;
+typedef struct pt_encpool {
+	pthread_t thread[PT_ENCODERS];
+	pthread_mutex_t lock;
+	pthread_cond_t wake, room;
+	pt_encjob *head, *tail;
+	int pending, quit, started;
+} pt_encpool;
+
 typedef struct pt_backend {
 	int n;
 	pt_ctx *ctx[PT_MAX_GPUS];
+	int imgW[PT_MAX_GPUS], imgH[PT_MAX_GPUS];   /* size of each context's accumulator */
+	/* frame pipeline (PT_PIPELINE=k, k = 1..PT_MAX_PIPE): k worker threads per GPU, each with its own
+	 * context and stream, frames dealt round-robin.  k = 2 lets two small frames share one GPU: a
+	 * 640x360 frame is 3600 waves, under half of the 8192 an MI355X holds. */
+	int pipeline;
+	long frameNo;
+	pt_worker worker[PT_MAX_GPUS * PT_MAX_PIPE];
+	pt_ctx *extra[PT_MAX_GPUS * PT_MAX_PIPE];   /* contexts of the workers beyond the first per GPU */
+	pt_encpool enc;
 } pt_backend;
 
 /* printf + append to log.txt in the CWD, like the reference's msg() (include/k_util.h:96-113) */
@@ -92,8 +141,13 @@ static uint32_t seed_stream_next(void) {
 /* test hook (not part of renderer.h): next value of the seed stream */
 unsigned int pt_seed_stream_next(void) { return seed_stream_next(); }
 
+static void pipeline_drain(pt_backend *b);
+static void pipeline_stop(pt_backend *b);
+
 static void backend_destroy(pt_backend *b) {
 	if(!b) return;
+	pipeline_stop(b);
+	for(int i = 0; i < PT_MAX_GPUS * PT_MAX_PIPE; i++) pt_ctx_destroy(b->extra[i]);
 	for(int i = 0; i < b->n; i++) pt_ctx_destroy(b->ctx[i]);
 	free(b);
 }
@@ -126,6 +180,10 @@ Renderer *create_renderer() {
 		}
 		b->n = i + 1;
 	}
+	const char *pipe = getenv("PT_PIPELINE");
+	b->pipeline = pipe ? atoi(pipe) : 0;
+	if(b->pipeline < 0) b->pipeline = 0;
+	if(b->pipeline > PT_MAX_PIPE) b->pipeline = PT_MAX_PIPE;
 	renderer->backend = b;
 	return renderer;
 }
@@ -135,10 +193,13 @@ void set_image_properties(Renderer *renderer, int width, int height, int maxRayD
 	renderer->imageInfo.size.y = height;
 	renderer->imageInfo.maxRayDepth = maxRayDepth;
 	pt_backend *b = renderer->backend;
+	if(b) pipeline_drain(b);
 	/* the reference leaks the old buffer when called twice (src/c/renderer.c:103); pt_image_alloc frees it */
-	for(int i = 0; b && i < b->n; i++)
+	for(int i = 0; b && i < b->n; i++) {
 		if(pt_image_alloc(b->ctx[i], width, height) != PT_OK)
 			host_msg("set_image_properties: %s\n", pt_last_error());
+		else { b->imgW[i] = width; b->imgH[i] = height; }
+	}
 }
 
 void clear_scene(Renderer *renderer) {
@@ -206,6 +267,18 @@ static float *flatten_scene(const Renderer *r) {
 	return out;
 }
 
+/* kernel arguments 1..3 of the reference's launch (src/c/renderer.c:160-162) */
+static void fill_render_args(pt_render_args *a, const Renderer *renderer) {
+	memset(a, 0, sizeof *a);
+	a->width = renderer->imageInfo.size.x; a->height = renderer->imageInfo.size.y;
+	a->max_depth = renderer->imageInfo.maxRayDepth;
+	a->background[0] = renderer->sceneInfo.color.x; a->background[1] = renderer->sceneInfo.color.y; a->background[2] = renderer->sceneInfo.color.z;
+	a->cam_pos[0] = renderer->camera.pos.x; a->cam_pos[1] = renderer->camera.pos.y; a->cam_pos[2] = renderer->camera.pos.z;
+	a->cam_rot[0] = renderer->camera.rot.x; a->cam_rot[1] = renderer->camera.rot.y; a->cam_rot[2] = renderer->camera.rot.z;
+	a->sensor_width = renderer->camera.sensorWidth; a->focal_length = renderer->camera.focalLength;
+	a->aperture = renderer->camera.aperture; a->exposure = renderer->camera.exposure;
+}
+
 static Image *render_failed(Renderer *renderer, const char *what) {
 	host_msg("%s: %s\n", what, pt_last_error());
 	destroy_renderer(renderer);   /* as src/c/renderer.c:244-249 */
@@ -215,6 +288,7 @@ static Image *render_failed(Renderer *renderer, const char *what) {
 Image *render(Renderer *renderer, int samples, int verbose) {
 	pt_backend *b = renderer->backend;
 	if(!b || b->n < 1) return NULL;
+	pipeline_drain(b);   /* frames queued by render_to_file() own the contexts until they are done */
 	const int W = renderer->imageInfo.size.x, H = renderer->imageInfo.size.y;
 	const int n = renderer->sceneInfo.sphereCount;
 	if(samples < 0) samples = 0;
@@ -230,14 +304,14 @@ Image *render(Renderer *renderer, int samples, int verbose) {
 	if(!seeds) return NULL;
 	for(int k = 0; k < samples; k++) seeds[k] = (uint64_t)seed_stream_next();
 
+	/* a pipelined frame of another size may have resized a context's accumulator */
+	for(int i = 0; i < b->n; i++)
+		if(b->imgW[i] != W || b->imgH[i] != H) {
+			if(pt_image_alloc(b->ctx[i], W, H) != PT_OK) { free(seeds); return render_failed(renderer, "image"); }
+			b->imgW[i] = W; b->imgH[i] = H;
+		}
 	pt_render_args a;
-	memset(&a, 0, sizeof a);
-	a.width = W; a.height = H; a.max_depth = renderer->imageInfo.maxRayDepth;
-	a.background[0] = renderer->sceneInfo.color.x; a.background[1] = renderer->sceneInfo.color.y; a.background[2] = renderer->sceneInfo.color.z;
-	a.cam_pos[0] = renderer->camera.pos.x; a.cam_pos[1] = renderer->camera.pos.y; a.cam_pos[2] = renderer->camera.pos.z;
-	a.cam_rot[0] = renderer->camera.rot.x; a.cam_rot[1] = renderer->camera.rot.y; a.cam_rot[2] = renderer->camera.rot.z;
-	a.sensor_width = renderer->camera.sensorWidth; a.focal_length = renderer->camera.focalLength;
-	a.aperture = renderer->camera.aperture; a.exposure = renderer->camera.exposure;
+	fill_render_args(&a, renderer);
 	a.world = b->n; a.band_rows = PT_BAND_ROWS;
 	a.async = 1;
 
@@ -292,7 +366,189 @@ Image *render(Renderer *renderer, int samples, int verbose) {
 	return image;
 }
 
+/* ---- frame pipeline (scripts/main.lua:25-98 renders 301 frames back to back) ----
+ * With PT_PIPELINE=1 render_to_file() only QUEUES the frame: a worker thread per GPU uploads the copied
+ * scene, renders, reads the 8-bit image back and encodes the file while the caller builds the next frame,
+ * and with several GPUs (PT_NUM_GPUS) whole frames are dealt round-robin instead of cutting each frame
+ * into bands.  Seeds are drawn here, at call time, so every frame gets exactly the seeds it would get
+ * without the pipeline.  Files are complete when destroy_renderer(), render() or set_image_properties()
+ * returns.  Off by default: the file is then on disk when render_to_file() returns, as in the reference. */
+static void *encoder_main(void *arg) {
+	pt_encpool *e = arg;
+	for(;;) {
+		pthread_mutex_lock(&e->lock);
+		while(!e->head && !e->quit) pthread_cond_wait(&e->wake, &e->lock);
+		pt_encjob *j = e->head;
+		if(!j) { pthread_mutex_unlock(&e->lock); return NULL; }
+		e->head = j->next;
+		if(!e->head) e->tail = NULL;
+		pthread_mutex_unlock(&e->lock);
+		write_image(&j->image, j->fileName);
+		free(j->image.data); free(j->fileName); free(j);
+		pthread_mutex_lock(&e->lock);
+		e->pending--;
+		pthread_cond_broadcast(&e->room);
+		pthread_mutex_unlock(&e->lock);
+	}
+}
+
+static void encode_submit(pt_encpool *e, Image *image, const char *fileName) {
+	pt_encjob *j = calloc(1, sizeof *j);
+	char *name = strdup(fileName);
+	if(!j || !name) {   /* out of memory: encode here */
+		write_image(image, (char *)fileName);
+		free(image->data); free(j); free(name);
+		return;
+	}
+	j->image = *image; j->fileName = name;
+	pthread_mutex_lock(&e->lock);
+	while(e->pending >= PT_ENCODE_QUEUE) pthread_cond_wait(&e->room, &e->lock);
+	if(e->tail) e->tail->next = j; else e->head = j;
+	e->tail = j;
+	e->pending++;
+	pthread_cond_signal(&e->wake);
+	pthread_mutex_unlock(&e->lock);
+}
+
+static void job_free(pt_job *j) {
+	if(!j) return;
+	free(j->flat); free(j->seeds); free(j->fileName); free(j);
+}
+
+static void job_run(pt_worker *w, pt_job *j) {
+	const int W = j->args.width, H = j->args.height;
+	if(pt_scene_upload(w->ctx, j->flat, j->n) != PT_OK) { host_msg("frame %s: scene upload: %s\n", j->fileName, pt_last_error()); return; }
+	if(w->imgW != W || w->imgH != H) {
+		if(pt_image_alloc(w->ctx, W, H) != PT_OK) { host_msg("frame %s: image: %s\n", j->fileName, pt_last_error()); return; }
+		w->imgW = W; w->imgH = H;
+	}
+	j->args.seeds = j->seeds; j->args.first_frame = 0; j->args.n_frames = j->samples;
+	j->args.rank = 0; j->args.world = 1; j->args.band_rows = PT_BAND_ROWS; j->args.async = 0;
+	if(j->samples == 0) { if(pt_image_alloc(w->ctx, W, H) != PT_OK) return; }
+	else if(pt_render(w->ctx, &j->args) != PT_OK) { host_msg("frame %s: render: %s\n", j->fileName, pt_last_error()); return; }
+	Image image;
+	image.width = W; image.height = H;
+	image.data = malloc(3 * (size_t)W * (size_t)H);
+	if(!image.data) return;
+	if(pt_image_read_u8(w->ctx, NULL, 0, 0, image.data) != PT_OK) {
+		host_msg("frame %s: read-back: %s\n", j->fileName, pt_last_error());
+		free(image.data);
+		return;
+	}
+	encode_submit(w->enc, &image, j->fileName);   /* takes ownership of image.data */
+}
+
+static void *worker_main(void *arg) {
+	pt_worker *w = arg;
+	for(;;) {
+		pthread_mutex_lock(&w->lock);
+		while(!w->head && !w->quit) pthread_cond_wait(&w->wake, &w->lock);
+		pt_job *j = w->head;
+		if(!j) { pthread_mutex_unlock(&w->lock); return NULL; }
+		w->head = j->next;
+		if(!w->head) w->tail = NULL;
+		pthread_mutex_unlock(&w->lock);
+		job_run(w, j);
+		job_free(j);
+		pthread_mutex_lock(&w->lock);
+		w->pending--;
+		pthread_cond_broadcast(&w->room);
+		pthread_mutex_unlock(&w->lock);
+	}
+}
+
+static void pipeline_drain(pt_backend *b) {
+	for(int i = 0; i < PT_MAX_GPUS * PT_MAX_PIPE; i++) {
+		pt_worker *w = &b->worker[i];
+		if(!w->started) continue;
+		pthread_mutex_lock(&w->lock);
+		while(w->pending > 0) pthread_cond_wait(&w->room, &w->lock);
+		pthread_mutex_unlock(&w->lock);
+		/* the worker may have resized its accumulator; render() re-allocates on mismatch below */
+		if(i < b->n) { b->imgW[i] = w->imgW; b->imgH[i] = w->imgH; }
+	}
+	if(b->enc.started) {
+		pthread_mutex_lock(&b->enc.lock);
+		while(b->enc.pending > 0) pthread_cond_wait(&b->enc.room, &b->enc.lock);
+		pthread_mutex_unlock(&b->enc.lock);
+	}
+}
+
+static void pipeline_stop(pt_backend *b) {
+	pipeline_drain(b);
+	for(int i = 0; i < PT_MAX_GPUS * PT_MAX_PIPE; i++) {
+		pt_worker *w = &b->worker[i];
+		if(!w->started) continue;
+		pthread_mutex_lock(&w->lock);
+		w->quit = 1;
+		pthread_cond_broadcast(&w->wake);
+		pthread_mutex_unlock(&w->lock);
+		pthread_join(w->thread, NULL);
+		pthread_mutex_destroy(&w->lock); pthread_cond_destroy(&w->wake); pthread_cond_destroy(&w->room);
+		w->started = 0;
+	}
+	if(b->enc.started) {
+		pthread_mutex_lock(&b->enc.lock);
+		b->enc.quit = 1;
+		pthread_cond_broadcast(&b->enc.wake);
+		pthread_mutex_unlock(&b->enc.lock);
+		for(int i = 0; i < b->enc.started; i++) pthread_join(b->enc.thread[i], NULL);
+		pthread_mutex_destroy(&b->enc.lock); pthread_cond_destroy(&b->enc.wake); pthread_cond_destroy(&b->enc.room);
+		b->enc.started = 0;
+	}
+}
+
+static int pipeline_submit(Renderer *renderer, int samples, const char *fileName) {
+	pt_backend *b = renderer->backend;
+	pt_job *j = calloc(1, sizeof *j);
+	if(!j) return 0;
+	if(samples < 0) samples = 0;
+	j->n = renderer->sceneInfo.sphereCount;
+	j->flat = flatten_scene(renderer);
+	j->samples = samples;
+	j->seeds = malloc(sizeof(uint64_t) * (size_t)(samples > 0 ? samples : 1));
+	j->fileName = strdup(fileName);
+	if(!j->flat || !j->seeds || !j->fileName) { job_free(j); return 0; }
+	for(int k = 0; k < samples; k++) j->seeds[k] = (uint64_t)seed_stream_next();   /* call order = frame order */
+	fill_render_args(&j->args, renderer);
+	if(!b->enc.started) {
+		pthread_mutex_init(&b->enc.lock, NULL); pthread_cond_init(&b->enc.wake, NULL); pthread_cond_init(&b->enc.room, NULL);
+		b->enc.head = b->enc.tail = NULL; b->enc.pending = 0; b->enc.quit = 0;
+		for(int i = 0; i < PT_ENCODERS; i++)
+			if(pthread_create(&b->enc.thread[i], NULL, encoder_main, &b->enc) == 0) b->enc.started++;
+		if(!b->enc.started) { job_free(j); return 0; }
+	}
+	const int g = (int)(b->frameNo++ % (b->n * b->pipeline));   /* worker g drives GPU g % n */
+	pt_worker *w = &b->worker[g];
+	if(!w->started) {
+		if(g < b->n) { w->ctx = b->ctx[g]; w->imgW = b->imgW[g]; w->imgH = b->imgH[g]; }
+		else {
+			if(!b->extra[g] && pt_ctx_create(g % b->n, &b->extra[g]) != PT_OK) {
+				host_msg("frame pipeline: %s\n", pt_last_error());
+				job_free(j);
+				return 0;
+			}
+			w->ctx = b->extra[g]; w->imgW = w->imgH = 0;
+		}
+		w->enc = &b->enc;
+		pthread_mutex_init(&w->lock, NULL); pthread_cond_init(&w->wake, NULL); pthread_cond_init(&w->room, NULL);
+		w->head = w->tail = NULL; w->pending = 0; w->quit = 0;
+		if(pthread_create(&w->thread, NULL, worker_main, w) != 0) { job_free(j); return 0; }
+		w->started = 1;
+	}
+	pthread_mutex_lock(&w->lock);
+	while(w->pending >= PT_PIPE_DEPTH) pthread_cond_wait(&w->room, &w->lock);
+	if(w->tail) w->tail->next = j; else w->head = j;
+	w->tail = j;
+	w->pending++;
+	pthread_cond_signal(&w->wake);
+	pthread_mutex_unlock(&w->lock);
+	return 1;
+}
+
 void render_to_file(Renderer *renderer, int samples, char *fileName, int verbose) {
+	pt_backend *b = renderer->backend;
+	if(b && b->pipeline && b->n >= 1 && !verbose && pipeline_submit(renderer, samples, fileName)) return;
 	Image *image = render(renderer, samples, verbose);
 	if(!image) return;   /* the reference dereferences NULL here (src/c/renderer.c:288-290); we do not */
 	write_image(image, fileName);

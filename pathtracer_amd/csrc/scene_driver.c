@@ -10,8 +10,15 @@
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <sys/time.h>
 
 #include "renderer.h"
+
+static double now_sec(void) {
+	struct timeval tv;
+	gettimeofday(&tv, NULL);
+	return (double)tv.tv_sec + 1e-6 * (double)tv.tv_usec;
+}
 
 int main(int argc, char **argv) {
 	int first = argc > 1 ? atoi(argv[1]) : 0;
@@ -23,7 +30,9 @@ int main(int argc, char **argv) {
 	const char *pattern = argc > 7 ? argv[7] : "clip/frame%d.png";
 	const double wallRadius = 10000, frames = 300, pi = 3.14159265358979323846;
 
+	const double t0 = now_sec();
 	Renderer *r = create_renderer();
+	const double t1 = now_sec();
 	set_image_properties(r, width, height, maxDepth);
 	set_background_color(r, 0, 0, 0);
 
@@ -58,6 +67,11 @@ int main(int argc, char **argv) {
 		snprintf(name, sizeof name, pattern, i);
 		render_to_file(r, samples, name, 0);
 	}
+	const double t2 = now_sec();
 	destroy_renderer(r);
+	const double t3 = now_sec();
+	if(getenv("PT_DRIVER_TIMING"))
+		fprintf(stderr, "create_renderer %.3f s, %d frames queued/rendered %.3f s, destroy_renderer (drains the pipeline) %.3f s\n",
+		        t1 - t0, count, t2 - t1, t3 - t2);
 	return 0;
 }

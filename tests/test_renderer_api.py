@@ -80,17 +80,19 @@ def test_struct_layouts_match_the_reference():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("ngpus", [1])
-def test_scene_driver_frames_match_oracle(tmp_path, oracle, ngpus):
-    """Two animation frames through create_renderer/…/render_to_file in a fresh process: the PNGs
-    must hold exactly the oracle's 8-bit image; the second frame continues the rand() seed stream."""
+@pytest.mark.parametrize("pipeline", [0, 1])
+def test_scene_driver_frames_match_oracle(tmp_path, oracle, pipeline):
+    """Animation frames through create_renderer/…/render_to_file in a fresh process: the PNGs must hold
+    exactly the oracle's 8-bit image; every frame continues the rand() seed stream.  pipeline=1: the
+    frames are queued to the worker thread (PT_PIPELINE) — same files."""
     W, H, spp = 96, 54, 8
-    env = dict(os.environ, PT_NUM_GPUS=str(ngpus))
+    frames = (3, 4, 5, 6, 7) if pipeline else (3, 4)
+    env = dict(os.environ, PT_NUM_GPUS="1", PT_PIPELINE=str(pipeline))
     pat = str(tmp_path / "frame%d.png")
-    subprocess.check_call([os.path.join(PKG, "pt_scene_driver"), "3", "2", str(W), str(H), str(spp), "50", pat],
+    subprocess.check_call([os.path.join(PKG, "pt_scene_driver"), "3", str(len(frames)), str(W), str(H), str(spp), "50", pat],
                           env=env, cwd=str(tmp_path), timeout=100)
-    stream = seedmod.glibc_rand_stream(2 * spp)
-    for k, i in enumerate((3, 4)):
+    stream = seedmod.glibc_rand_stream(len(frames) * spp)
+    for k, i in enumerate(frames):
         sc = scenes.main_lua_frame(i)
         want = oracle.postprocess(oracle.render(sc, W, H, 50, stream[k * spp:(k + 1) * spp])).reshape(H, W, 3)
         got = read_png_rgb8(pat % i)
