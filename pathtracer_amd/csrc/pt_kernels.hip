@@ -35,7 +35,8 @@ struct KParams {
 	float sensorWidth, focalLength, aperture, exposure;
 	int firstFrame, nFrames;
 	int rank, world, bandRows;          // row-band partition (pt_hip.h)
-	int localPixels;                    // pixels of this rank = threads that do work
+	int localPixels;                    // pixels of this rank
+	int logS;                           // LDS kernel: 2^logS lanes share a pixel (sample-interleaved)
 };
 
 // Device scene tables (SoA).  geom[i] = {cx, cy, cz, r*r}; matA[i] = {colr, colg, colb, type bits};
@@ -398,7 +399,18 @@ __global__ __launch_bounds__(256) void pt_render_lds_kernel(float4 *__restrict__
 		sMatB[i] = sc.matB[i];
 	}
 	__syncthreads();
-	const int id = pixel_id(p, (int)(blockIdx.x * blockDim.x + threadIdx.x));
+	// Sample-interleaved lanes: a pixel is served by S = 1 << p.logS adjacent lanes, lane `sub` tracing the
+	// samples k = sub (mod S).  The samples of a pixel are independent paths (src/cl/main.cl:6: the RNG
+	// stream depends on (id, seed_k) only); what is serial is the running mean, so after every round of S
+	// samples each lane collects the S colours by shuffles and accumulates them IN ORDER k, k+1, ...
+	// (every lane of the group redundantly, a few dozen instructions).  Bit-identical to S = 1; it only
+	// multiplies the number of waves for images that cannot fill the chip on their own (a 640x360 frame,
+	// or one GPU's bands of a 1080p frame split 8 ways, is ~4000 waves for 8192 wave slots).
+	const int S = 1 << p.logS;
+	const int thread = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+	const int sub = thread & (S - 1);
+	const int groupBase = (int)(threadIdx.x & 63) & ~(S - 1);
+	const int id = pixel_id(p, thread >> p.logS);
 	unsigned int myBounces = 0;
 	if(id >= 0) {
 		const f3 origin = camera_origin(p, id);
@@ -407,21 +419,35 @@ __global__ __launch_bounds__(256) void pt_render_lds_kernel(float4 *__restrict__
 			float4 v = image[id];
 			acc = mk3(v.x, v.y, v.z);
 		}
-		for(int k = 0; k < p.nFrames; k++) {
-			Path pt;
-			start_sample(pt, p, id, origin, seedmul[k]);
+		for(int k0 = 0; k0 < p.nFrames; k0 += S) {
+			const int k = k0 + sub;
 			f3 color = mk3(0.0f, 0.0f, 0.0f);                                            // ray.cl:92
-			for(int j = 0; j < p.maxDepth; j++) {                                        // ray.cl:96
-				if(COUNT) myBounces++;
-				const float ln = len3(pt.d);
-				const float a = ln * ln;                                                 // ray.cl:73 pow(length(d),2)
-				const Hit h = closest_hit(sGeom, p.n, pt.o, pt.d, a);
-				if(!h.hit) { color = mul3(pt.mask, mk3(p.bgx, p.bgy, p.bgz)); break; }   // ray.cl:112-115
-				if(shade_hit(pt, h.t, sGeom[h.idx], sMatA[h.idx], sMatB[h.idx], color)) break;
+			if(k < p.nFrames) {
+				Path pt;
+				start_sample(pt, p, id, origin, seedmul[k]);
+				for(int j = 0; j < p.maxDepth; j++) {                                    // ray.cl:96
+					if(COUNT) myBounces++;
+					const float ln = len3(pt.d);
+					const float a = ln * ln;                                             // ray.cl:73 pow(length(d),2)
+					const Hit h = closest_hit(sGeom, p.n, pt.o, pt.d, a);
+					if(!h.hit) { color = mul3(pt.mask, mk3(p.bgx, p.bgy, p.bgz)); break; }   // ray.cl:112-115
+					if(shade_hit(pt, h.t, sGeom[h.idx], sMatA[h.idx], sMatB[h.idx], color)) break;
+				}
 			}
-			acc = accumulate(acc, color, p, p.firstFrame + k);
+			if(S == 1) acc = accumulate(acc, color, p, p.firstFrame + k0);
+			else {
+				const int round = p.nFrames - k0 < S ? p.nFrames - k0 : S;
+				for(int s = 0; s < round; s++) {
+					const f3 c = mk3(__shfl(color.x, groupBase + s, 64), __shfl(color.y, groupBase + s, 64), __shfl(color.z, groupBase + s, 64));
+					acc = accumulate(acc, c, p, p.firstFrame + k0 + s);
+				}
+			}
 		}
-		image[id] = make_float4(acc.x, acc.y, acc.z, COUNT ? (float)myBounces : 0.0f);
+		if(COUNT && S > 1) {
+			unsigned int v = myBounces, tot = 0;
+			for(int s = 0; s < S; s++) tot += (unsigned int)__shfl((int)v, groupBase + s, 64);
+			if(sub == 0) image[id] = make_float4(acc.x, acc.y, acc.z, (float)tot);
+		} else if(sub == 0) image[id] = make_float4(acc.x, acc.y, acc.z, COUNT ? (float)myBounces : 0.0f);
 	}
 	if(COUNT) {
 		unsigned int v = myBounces;
@@ -828,7 +854,17 @@ extern "C" int pt_render(pt_ctx *c, const pt_render_args *a) {
 	if(lp == 0) return PT_OK;
 
 	SceneTables sc = {c->geom, c->matA, c->matB};
-	dim3 block(256), grid((unsigned)((lp + 255) / 256));
+	// LDS kernel: enough lanes per pixel that the launch has about a dozen rounds of the chip's 8192 wave
+	// slots (measured on the 1080p headline frame: 243 ms at 1 lane per pixel, 231 ms at 4; 640x360: 289 -> 218 ms at 8)
+	p.logS = 0;
+	{
+		const char *fs = getenv("PT_LANES_PER_PIXEL");      // debugging aid: force 1, 2, 4 or 8
+		int want = 0;
+		if(fs) { int v = atoi(fs); while((1 << want) < v && want < 3) want++; }
+		else while(want < 3 && (lp << want) < 64ll * 12 * 8192 && (2 << want) <= a->n_frames) want++;
+		p.logS = want;
+	}
+	dim3 block(256), grid((unsigned)(((lp << p.logS) + 255) / 256));
 	// tables of up to PT_LDS_MAX_SPHERES spheres (48 B each) are staged whole in LDS
 	const char *force = getenv("PT_KERNEL");      // debugging aid: "v1" forces the first, scalar-load kernel
 	const bool useV1 = force && strcmp(force, "v1") == 0;

@@ -23,6 +23,7 @@ def main():
     depth = int(a[3]) if len(a) > 3 else 50
     W = int(a[4]) if len(a) > 4 else 1920
     H = int(a[5]) if len(a) > 5 else 1080
+    world = int(a[6]) if len(a) > 6 else 1       # render only rank 0's bands of a `world`-way split
     sc = SCENES[name]()
     s = seedmod.glibc_rand_stream(spp)
     ctx = hip.Context(0)
@@ -34,10 +35,10 @@ def main():
         print("bounce iterations per sample: %.3f (over %d spp)" % (bc / (W * H * len(cs)), len(cs)), flush=True)
     for r in range(reps):
         t0 = time.perf_counter()
-        ms = ctx.render(sc, W, H, depth, s, time_kernel=True)
+        ms = ctx.render(sc, W, H, depth, s, time_kernel=True, world=world, band_rows=8)
         dt = time.perf_counter() - t0
         print("%s %dx%d spp %d depth %d: kernel %.3f ms (wall %.3f ms) -> %.1f Msamples/s" %
-              (name, W, H, spp, depth, ms, dt * 1e3, W * H * spp / ms / 1e3), flush=True)
+              (name, W, H, spp, depth, ms, dt * 1e3, W * H * spp / world / ms / 1e3), flush=True)
     ctx.close()
 
 
