@@ -64,6 +64,8 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="debug: run the multi-rank code path (process group, zero-fill, RCCL reduce, barrier) even with one rank")
     ap.add_argument("--spp", type=int, default=SPP, help="debug only: any value but %d is not the benchmark" % SPP)
     args = ap.parse_args()
 
@@ -80,9 +82,13 @@ def main():
         raise SystemExit("bench.py: no GPU visible — this benchmark has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    multi = world > 1 or args.force_dist
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", str(rank))
+        os.environ.setdefault("WORLD_SIZE", str(world))
+        dist.init_process_group("nccl", rank=rank, world_size=world)
 
     spp = args.spp
     scene = scenes.main_lua_frame(0)
@@ -102,11 +108,11 @@ def main():
     assert stream != 0
 
     def step(count=False):
-        if world > 1:
+        if multi:
             frame.zero_()
         bc = ctx.render(scene, WIDTH, HEIGHT, DEPTH, seeds, rank=rank, world=world, band_rows=BAND_ROWS,
                         d_image=frame.data_ptr(), stream=stream, count_bounces=count, async_=True)
-        if world > 1:
+        if multi:
             dist.reduce(frame, dst=0, op=dist.ReduceOp.SUM)
         return bc
 
@@ -116,8 +122,8 @@ def main():
         step()
 
     def barrier():
-        if world > 1:
-            dist.barrier()
+        if multi:
+            dist.barrier(device_ids=[local_rank])
         torch.cuda.synchronize()
 
     if args.steps > 256:
@@ -125,12 +131,12 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for k in range(args.steps):
-        if world > 1:
+        if multi:
             frame.zero_()
         # record_timing: the C ABI brackets the kernel with HIP events on the launch stream, no host sync
         ctx.render(scene, WIDTH, HEIGHT, DEPTH, seeds, rank=rank, world=world, band_rows=BAND_ROWS,
                    d_image=frame.data_ptr(), stream=stream, async_=True, record_timing=True)
-        if world > 1:
+        if multi:
             dist.reduce(frame, dst=0, op=dist.ReduceOp.SUM)
     barrier()
     dt = time.perf_counter() - t0
@@ -139,7 +145,7 @@ def main():
     assert len(kern_times) == args.steps, (len(kern_times), args.steps)
     kern_ms = float(np.mean(kern_times))
     tb = torch.tensor([float(my_bounces), dt, kern_ms], dtype=torch.float64, device=dev)
-    if world > 1:
+    if multi:
         tsum = tb.clone()
         dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
         tmax = tb.clone()
@@ -184,8 +190,13 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene, seedmod.glibc_rand_stream(SPP))
         print(json.dumps(out), flush=True)
+    if multi and rank == 0:
+        # the reduced frame on rank 0 is the whole image: the counting launch left every pixel's bounce count in
+        # the 4th lane only in the untimed step, so check the colour lanes are populated in every band
+        rows = frame[::BAND_ROWS, :, :3].abs().sum(dim=(1, 2))
+        assert bool((rows > 0).all()), "bench.py: a row band is empty after the reduce"
     ctx.close()
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 
