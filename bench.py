@@ -64,6 +64,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fast-math", action="store_true", help="skip the extra, untimed measurement of the relaxed-float build")
     ap.add_argument("--force-dist", action="store_true",
                     help="debug: run the multi-rank code path (process group, zero-fill, RCCL reduce, barrier) even with one rank")
     ap.add_argument("--spp", type=int, default=SPP, help="debug only: any value but %d is not the benchmark" % SPP)
@@ -144,6 +145,16 @@ def main():
     kern_times = ctx.kernel_times()
     assert len(kern_times) == args.steps, (len(kern_times), args.steps)
     kern_ms = float(np.mean(kern_times))
+
+    # untimed extra (rank-local, N=1 only): the opt-in relaxed-float build of the same kernel, for the roofline
+    # discussion — NOT the reported value, its image is within tolerance of the oracle, not bit-identical
+    fast_ms = None
+    if world == 1 and not args.no_fast_math:
+        for _ in range(1 + min(args.steps, 3)):
+            ctx.render(scene, WIDTH, HEIGHT, DEPTH, seeds, d_image=frame.data_ptr(), stream=stream, async_=True,
+                       record_timing=True, fast_math=True)
+        torch.cuda.synchronize()
+        fast_ms = float(np.mean(ctx.kernel_times()[1:]))
     tb = torch.tensor([float(my_bounces), dt, kern_ms], dtype=torch.float64, device=dev)
     if multi:
         tsum = tb.clone()
@@ -187,6 +198,13 @@ def main():
                          "note": "FP32 vector roofline (no dense contraction on this path, SURVEY.md §8d); "
                                  "algorithmic FLOPs = B*(18N+34+30)+60 per sample with B measured in-kernel"},
         }
+        if fast_ms is not None:
+            out["fast_math"] = {"value": samples / (fast_ms * 1e-3) / 1e6, "unit": "Msamples/s", "kernel_ms": fast_ms,
+                                "frac": fps * samples / (fast_ms * 1e-3) / 1e12 / PEAK_FP32_VALU_TFLOPS,
+                                "note": "opt-in build of the same kernel (pt_render_args.fast_math / PT_MATH=fast): FMA contraction, "
+                                        "1-ulp v_sqrt_f32/v_rcp_f32, as the reference's own -cl-fast-relaxed-math allows; same RNG "
+                                        "stream, image within the tolerance of tests/test_gpu_fast_math.py, not bit-identical; "
+                                        "kernel time only, not the reported value"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene, seedmod.glibc_rand_stream(SPP))
         print(json.dumps(out), flush=True)

@@ -67,6 +67,11 @@ typedef struct pt_render_args {
 	int record_timing;        /* 1: bracket the render kernel with a pair of HIP events on the launch stream
 	                             WITHOUT synchronising; collect the durations later with pt_kernel_times().
 	                             At most 256 launches between two collections.  Ignored when kernel_ms is set. */
+	int fast_math;            /* 0 (default): strict IEEE arithmetic in the reference's operation order — the image
+	                             is bit-identical to the CPU oracle.  1: the freedoms of the reference's own build
+	                             options (-cl-mad-enable -cl-fast-relaxed-math, src/c/renderer.c:13): FMA
+	                             contraction, 1-ulp hardware sqrt and reciprocal; same RNG stream, image within
+	                             tolerance.  The environment variable PT_MATH=fast|strict overrides this field. */
 } pt_render_args;
 
 /* Text of the last error on this thread ("" if none). */

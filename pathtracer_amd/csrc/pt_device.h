@@ -11,9 +11,23 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-struct f3 { float x, y, z; };
+#ifndef PT_NS
+#error "include through pt_render_kernels.h (PT_NS and PT_FAST_MATH select the build)"
+#endif
 
 #define PT_DEV __device__ __forceinline__
+
+namespace PT_NS {
+
+struct f3 { float x, y, z; };
+
+// The two operations whose rounding the strict build pins (correctly rounded, as the x86 oracle's) and the
+// fast build relaxes to the 1-ulp hardware instructions.
+#if PT_FAST_MATH
+PT_DEV float pt_div(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+#else
+PT_DEV float pt_div(float a, float b) { return a / b; }
+#endif
 
 PT_DEV f3 mk3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
 PT_DEV f3 add3(f3 a, f3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
@@ -32,6 +46,9 @@ PT_DEV float dot3(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
 constexpr uint32_t PT_SQRT_TINY_BITS = 0x0f800000u;   // 2^-96
 PT_DEV float sqrt_nt(float x) {
 	float s = __builtin_amdgcn_sqrtf(x);
+#if PT_FAST_MATH
+	return s;
+#endif
 	float sm = __uint_as_float(__float_as_uint(s) - 1u);
 	float sp = __uint_as_float(__float_as_uint(s) + 1u);
 	float rm = __builtin_fmaf(-sm, s, x);
@@ -45,12 +62,15 @@ PT_DEV float sqrt_nt(float x) {
 // (practically never taken) branch for 0 < x < 2^-96.
 PT_DEV float sqrt_cr(float x) {
 	float s = sqrt_nt(x);
+#if PT_FAST_MATH
+	return s;
+#endif
 	if(__builtin_expect((__float_as_uint(x) & 0x7fffffffu) - 1u < PT_SQRT_TINY_BITS - 1u, 0)) s = sqrtf(x);
 	return s;
 }
 
 PT_DEV float len3(f3 a) { return sqrt_cr(dot3(a, a)); }
-PT_DEV f3 norm3(f3 a) { float inv = 1.0f / len3(a); return scl3(a, inv); }
+PT_DEV f3 norm3(f3 a) { float inv = pt_div(1.0f, len3(a)); return scl3(a, inv); }
 
 constexpr uint32_t PT_M31 = 2147483647u;   // MINSTD modulus 2^31 - 1 (src/cl/rng.cl:12)
 
@@ -102,6 +122,10 @@ PT_DEV f3 reflection_dir(f3 in, f3 n) { return sub3(in, scl3(scl3(n, 2.0f), dot3
 // pow(x,5) of oracle/ref_shim.cpp = (float)pow((double)x,5.0): x^5 in f64 (x^2 exact, two
 // roundings after) narrowed to f32 — identical except on a ~2^-29 double-rounding sliver.
 PT_DEV float pow5(float x) {
+#if PT_FAST_MATH
+	const float x2 = x * x;
+	return x2 * x2 * x;
+#endif
 	double d = (double)x;
 	double d2 = d * d;
 	double d4 = d2 * d2;
@@ -110,7 +134,7 @@ PT_DEV float pow5(float x) {
 
 // src/cl/ray.cl:58-62 — Schlick
 PT_DEV float reflectance(float cosTheta, float rel) {
-	float r = (1.0f - rel) / (1.0f + rel);
+	float r = pt_div(1.0f - rel, 1.0f + rel);
 	r = r * r;
 	return r + (1.0f - r) * pow5(1.0f - cosTheta);
 }
@@ -123,3 +147,5 @@ PT_DEV f3 refraction_dir(f3 in, f3 n, float rel) {
 	f3 par = scl3(n, -sqrt_cr(fabsf(1.0f - lp * lp)));
 	return add3(par, perp);
 }
+
+}   // namespace PT_NS

@@ -17,588 +17,14 @@
 #include <stdlib.h>
 #include <string.h>
 
-#include "pt_device.h"
+#define PT_NS pt_strict
+#define PT_FAST_MATH 0
+#include "pt_render_kernels.h"
 #include "pt_hip.h"
 
-// ---------------------------------------------------------------------------------------
-// Kernel parameters (by value: land in SGPRs — the reference passes its three structs by
-// value too, src/c/renderer.c:160-162)
-// ---------------------------------------------------------------------------------------
+using namespace pt_strict;
+
 #define PT_TIMING_SLOTS 256
-#define PT_LDS_MAX_SPHERES 512   // 24 KB of LDS per 256-thread block: 6 blocks = 24 waves per CU still fit
-
-struct KParams {
-	int W, H, maxDepth, n;
-	float bgx, bgy, bgz;
-	float px, py, pz;                   // Camera.pos
-	float cosRx, sinRx, cosRy, sinRy;   // cosf/sinf of Camera.rot.x / .y, folded on the host (rot.z is dead, src/cl/ray.cl:42-43)
-	float sensorWidth, focalLength, aperture, exposure;
-	int firstFrame, nFrames;
-	int rank, world, bandRows;          // row-band partition (pt_hip.h)
-	int localPixels;                    // pixels of this rank
-	int logS;                           // LDS kernel: 2^logS lanes share a pixel (sample-interleaved)
-};
-
-// Device scene tables (SoA).  geom[i] = {cx, cy, cz, r*r}; matA[i] = {colr, colg, colb, type bits};
-// matB[i] = {tint, fuzz, refIdx, 0}.
-struct SceneTables {
-	const float4 *geom;
-	const float4 *matA;
-	const float4 *matB;
-};
-
-// Thread -> global work-item id under the row-band partition.  Returns -1 past the end.
-PT_DEV int pixel_id(const KParams &p, int t) {
-	if(t >= p.localPixels) return -1;
-	int lrow = t / p.W, col = t - lrow * p.W;
-	int lband = lrow / p.bandRows, rin = lrow - lband * p.bandRows;
-	int row = (lband * p.world + p.rank) * p.bandRows + rin;
-	return row < p.H ? row * p.W + col : -1;
-}
-
-// src/cl/main.cl:8-17 — the part of the camera ray that does not depend on the sample.
-PT_DEV f3 camera_origin(const KParams &p, int id) {
-	int row = id / p.W, column = id - row * p.W;
-	float aspect = (float)p.W / (float)p.H;
-	float xOff = 2.0f * (float)(column - p.W / 2) / (float)p.W * p.sensorWidth;
-	float yOff = 2.0f * (float)(row - p.H / 2) / (float)p.H * p.sensorWidth / aspect;
-	f3 v = mk3(-xOff, yOff, p.focalLength);
-	// rotate_vector as it nets out (src/cl/ray.cl:39-52)
-	f3 r = mk3(v.x * p.cosRy + v.z * p.sinRy, v.y * p.cosRx - v.z * p.sinRx, v.y * p.sinRx + v.z * p.cosRx);
-	return add3(mk3(p.px, p.py, p.pz), r);
-}
-
-// ---------------------------------------------------------------------------------------
-// Kernel v1: one thread per pixel, all samples in-kernel, lock-step sample loop.
-// ---------------------------------------------------------------------------------------
-template <bool COUNT>
-__global__ __launch_bounds__(256) void pt_render_kernel(float4 *__restrict__ image, const KParams p, const SceneTables sc,
-                                                         const uint64_t *__restrict__ seedmul,
-                                                         unsigned long long *__restrict__ bounceCounter) {
-	const int id = pixel_id(p, (int)(blockIdx.x * blockDim.x + threadIdx.x));
-	unsigned int myBounces = 0;
-	if(id >= 0) {
-		const f3 pos = mk3(p.px, p.py, p.pz);
-		const f3 origin = camera_origin(p, id);
-		f3 acc = mk3(0.0f, 0.0f, 0.0f);
-		if(p.firstFrame > 0) {
-			float4 v = image[id];
-			acc = mk3(v.x, v.y, v.z);
-		}
-		for(int k = 0; k < p.nFrames; k++) {
-			uint32_t rng = init_rng_2((uint32_t)id, seedmul[k]);                       // main.cl:6
-			f3 target = add3(pos, scl3(random_unit_vector(rng), p.aperture));            // main.cl:19
-			f3 d = norm3(sub3(target, origin));                                          // main.cl:21
-			f3 o = pos;                                                                  // main.cl:23
-			f3 color = mk3(0.0f, 0.0f, 0.0f), mask = mk3(1.0f, 1.0f, 1.0f);              // ray.cl:92-93
-			for(int j = 0; j < p.maxDepth; j++) {                                        // ray.cl:96
-				if(COUNT) myBounces++;
-				const float ln = len3(d);
-				const float a = ln * ln;                                                 // ray.cl:73 pow(length(d),2)
-				bool hit = false;
-				float distance = 0.0f;
-				int idx = 0;
-				for(int i = 0; i < p.n; i++) {                                           // ray.cl:101-110
-					const float4 g = sc.geom[i];
-					const f3 oc = sub3(o, mk3(g.x, g.y, g.z));
-					const float bHalf = dot3(oc, d);
-					const float c = oc.x * oc.x + oc.y * oc.y + oc.z * oc.z - g.w;
-					const float disc = bHalf * bHalf - a * c;
-					if(!(disc < 0.0f)) {
-						const float t = (-bHalf - sqrtf(disc)) / a;
-						if(t > 0.0f && (!hit || t < distance)) { hit = true; distance = t; idx = i; }
-					}
-				}
-				if(!hit) { color = mul3(mask, mk3(p.bgx, p.bgy, p.bgz)); break; }      // ray.cl:112-115
-				const float4 g = sc.geom[idx];
-				const float4 mA = sc.matA[idx];
-				const float4 mB = sc.matB[idx];
-				const int type = __float_as_int(mA.w);
-				const f3 mcol = mk3(mA.x, mA.y, mA.z);
-				const f3 hitPos = add3(o, scl3(d, distance));                            // ray.cl:117
-				f3 normal = norm3(sub3(hitPos, mk3(g.x, g.y, g.z)));                     // ray.cl:118
-				const f3 offPos = sub3(hitPos, scl3(normal, 0.0001f));                   // ray.cl:119
-				bool front = true;
-				if(dot3(d, normal) > 0.0f) { front = false; normal = scl3(normal, -1.0f); }   // ray.cl:122-128
-				if(type == 0) {                                                          // ray.cl:130-134
-					if(front) { color = mul3(mask, mcol); break; }
-				} else if(type == 1) {                                                   // ray.cl:136-141
-					if(front) {
-						d = add3(normal, random_unit_vector(rng));
-						o = offPos;
-						mask = mul3(mask, mcol);
-					}
-				} else if(type == 2) {                                                   // ray.cl:143-148
-					if(front) {
-						d = add3(reflection_dir(d, normal), scl3(random_unit_vector(rng), mB.y));
-						o = offPos;
-						mask = add3(scl3(mask, 1.0f - mB.x), scl3(mul3(mask, mcol), mB.x));
-					}
-				} else if(type == 3) {                                                   // ray.cl:150-171
-					const float rel = front ? mB.z : 1.0f / mB.z;
-					const float cosTheta = fminf(dot3(scl3(d, -1.0f), normal), 1.0f);
-					const float sinTheta = sqrtf(1.0f - cosTheta * cosTheta);
-					bool reflect = rel * sinTheta > 1.0f;
-					if(!reflect) reflect = reflectance(cosTheta, rel) > rand_float(rng);    // short-circuit draw, ray.cl:163
-					const f3 base = reflect ? reflection_dir(d, normal) : refraction_dir(d, normal, rel);
-					d = add3(base, scl3(random_unit_vector(rng), mB.y));
-					o = offPos;
-					mask = add3(scl3(mask, 1.0f - mB.x), scl3(mul3(mask, mcol), mB.x));
-				}
-			}
-			color = scl3(scl3(color, p.exposure), p.aperture);                           // main.cl:27
-			const float f = (float)(p.firstFrame + k), f1 = (float)(p.firstFrame + k + 1);
-			acc = mk3((acc.x * f + color.x) / f1, (acc.y * f + color.y) / f1, (acc.z * f + color.z) / f1);   // main.cl:29
-		}
-		image[id] = make_float4(acc.x, acc.y, acc.z, COUNT ? (float)myBounces : 0.0f);
-	}
-	if(COUNT) {
-		// wave-level sum, one atomic per wave
-		unsigned int v = myBounces;
-		for(int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-		if((threadIdx.x & 63) == 0 && v) atomicAdd(bounceCounter, (unsigned long long)v);
-	}
-}
-
-// ---------------------------------------------------------------------------------------
-// Per-path state and the pieces every kernel variant shares
-// ---------------------------------------------------------------------------------------
-struct Path {
-	f3 o, d;          // ray (direction NOT normalised after the first bounce, src/cl/ray.cl:138)
-	f3 mask;          // ray.cl:93
-	uint32_t rng;     // MINSTD state (src/cl/rng.cl)
-};
-
-// src/cl/main.cl:6,19-23 — RNG seeding and the primary ray of sample k of work-item id
-PT_DEV void start_sample(Path &pt, const KParams &p, int id, f3 origin, uint64_t xb) {
-	const f3 pos = mk3(p.px, p.py, p.pz);
-	pt.rng = init_rng_2((uint32_t)id, xb);                                               // main.cl:6
-	const f3 target = add3(pos, scl3(random_unit_vector(pt.rng), p.aperture));           // main.cl:19
-	pt.d = norm3(sub3(target, origin));                                                  // main.cl:21
-	pt.o = pos;                                                                          // main.cl:23
-	pt.mask = mk3(1.0f, 1.0f, 1.0f);                                                     // ray.cl:93
-}
-
-// src/cl/main.cl:27-29 — exposure scale and the running mean with frame = f
-PT_DEV f3 accumulate(f3 acc, f3 color, const KParams &p, int frame) {
-	color = scl3(scl3(color, p.exposure), p.aperture);                                   // main.cl:27
-	const float f = (float)frame, f1 = (float)(frame + 1);
-	return mk3((acc.x * f + color.x) / f1, (acc.y * f + color.y) / f1, (acc.z * f + color.z) / f1);   // main.cl:29
-}
-
-// src/cl/ray.cl:117-171 — everything after the closest hit is known.  Returns true when the path
-// ends here (front face of a light), with its colour in `color`.
-PT_DEV bool shade_hit(Path &pt, float t, const float4 g, const float4 mA, const float4 mB, f3 &color) {
-	const int type = __float_as_int(mA.w);
-	const f3 mcol = mk3(mA.x, mA.y, mA.z);
-	const f3 d = pt.d;
-	const f3 hitPos = add3(pt.o, scl3(d, t));                                            // ray.cl:117
-	f3 normal = norm3(sub3(hitPos, mk3(g.x, g.y, g.z)));                                 // ray.cl:118
-	const f3 offPos = sub3(hitPos, scl3(normal, 0.0001f));                               // ray.cl:119 (outward normal)
-	bool front = true;
-	if(dot3(d, normal) > 0.0f) { front = false; normal = scl3(normal, -1.0f); }          // ray.cl:122-128
-	if(type == 0) {                                                                      // ray.cl:130-134
-		if(front) { color = mul3(pt.mask, mcol); return true; }
-	} else if(type == 1) {                                                               // ray.cl:136-141
-		if(front) {
-			pt.d = add3(normal, random_unit_vector(pt.rng));
-			pt.o = offPos;
-			pt.mask = mul3(pt.mask, mcol);
-		}
-	} else if(type == 2) {                                                               // ray.cl:143-148
-		if(front) {
-			pt.d = add3(reflection_dir(d, normal), scl3(random_unit_vector(pt.rng), mB.y));
-			pt.o = offPos;
-			pt.mask = add3(scl3(pt.mask, 1.0f - mB.x), scl3(mul3(pt.mask, mcol), mB.x));
-		}
-	} else if(type == 3) {                                                               // ray.cl:150-171
-		const float rel = front ? mB.z : 1.0f / mB.z;
-		const float cosTheta = fminf(dot3(scl3(d, -1.0f), normal), 1.0f);
-		const float sinTheta = sqrt_cr(1.0f - cosTheta * cosTheta);
-		bool reflect = rel * sinTheta > 1.0f;
-		if(!reflect) reflect = reflectance(cosTheta, rel) > rand_float(pt.rng);          // short-circuit draw, ray.cl:163
-		const f3 base = reflect ? reflection_dir(d, normal) : refraction_dir(d, normal, rel);
-		pt.d = add3(base, scl3(random_unit_vector(pt.rng), mB.y));
-		pt.o = offPos;
-		pt.mask = add3(scl3(pt.mask, 1.0f - mB.x), scl3(mul3(pt.mask, mcol), mB.x));
-	}
-	return false;
-}
-
-// ---------------------------------------------------------------------------------------
-// Closest hit (src/cl/ray.cl:101-110 with hit_sphere, :71-87)
-// ---------------------------------------------------------------------------------------
-struct Hit { bool hit; float t; int idx; };
-
-// The reference scan, as written: sqrt and divide per candidate, strict `<` on the rounded distances.
-template <typename Tab>
-PT_DEV Hit closest_hit_reference(const Tab geom, int n, f3 o, f3 d, float a) {
-	Hit h; h.hit = false; h.t = 0.0f; h.idx = 0;
-	for(int i = 0; i < n; i++) {
-		const float4 g = geom[i];
-		const f3 oc = sub3(o, mk3(g.x, g.y, g.z));
-		const float bHalf = dot3(oc, d);
-		const float c = oc.x * oc.x + oc.y * oc.y + oc.z * oc.z - g.w;
-		const float disc = bHalf * bHalf - a * c;
-		if(!(disc < 0.0f)) {
-			const float t = (-bHalf - sqrtf(disc)) / a;
-			if(t > 0.0f && (!h.hit || t < h.t)) { h.hit = true; h.t = t; h.idx = i; }
-		}
-	}
-	return h;
-}
-
-// Branch-free scan with ONE divide per ray instead of one per candidate.  Same result as
-// closest_hit_reference for every input; the argument:
-//  * num_i = -bHalf_i - sqrt(disc_i) is computed exactly as the reference does (sqrt_nt == sqrtf
-//    unless 0 < |disc| < 2^-96; the scan keeps the smallest non-zero |disc| and raises `slow` below
-//    that).  A negative or NaN disc gives a NaN num.
-//  * With 2^-40 <= a <= 2^40 and 2^-80 <= num <= 2^80 the quotient t = num/a neither underflows nor
-//    overflows, so t > 0 <=> num > 0, and rounding is monotonic: num_i < num_j => t_i <= t_j.
-//    A NaN or non-positive num is no hit on both sides.  Outside those ranges: `slow`.
-//  * Positive floats order like their bit patterns, so key = bits(num) puts every valid num below
-//    KEY_NONE = bits(+inf) and negatives, NaNs and +inf at or above it.  num == +0 (t == 0: no hit in
-//    the reference) is the one invalid value that sorts first; it then wins the scan, is seen at the
-//    end (best == 0) and raises `slow`.  The scan keeps the smallest key with the lowest index (strict <), and `prev`, the
-//    smallest key among LOWER indices (the running minimum just before the last update).
-//  * The reference's winner is the lowest index among the spheres whose ROUNDED t is minimal.  That
-//    is our index unless a lower-indexed sphere with a larger num rounds to the same t; by
-//    monotonicity the smallest such num is `prev`, and if prev > num * (1 + 2^-21) the two quotients
-//    are more than an ulp apart.  Otherwise: `slow`.
-//  `slow` lanes re-run the reference scan (whole wave skips it when no lane asks).
-constexpr uint32_t KEY_NONE = 0x7f800000u;   // bits(+inf)
-
-// src/cl/ray.cl:72-76 — bHalf and the discriminant, in the reference's operation order
-PT_DEV void sphere_disc(const float4 g, f3 o, f3 d, float a, float &bHalf, float &disc) {
-	const f3 oc = sub3(o, mk3(g.x, g.y, g.z));
-	bHalf = dot3(oc, d);
-	const float c = oc.x * oc.x + oc.y * oc.y + oc.z * oc.z - g.w;
-	disc = bHalf * bHalf - a * c;
-}
-
-PT_DEV void candidate_update(float bHalf, float disc, int i, uint32_t &best, uint32_t &prev, int &idx, uint32_t &tiny) {
-	tiny = min(tiny, (__float_as_uint(disc) & 0x7fffffffu) - 1u);   // smallest non-zero |disc| seen (zero wraps to the top)
-	const float num = -bHalf - sqrt_nt(disc);
-	const uint32_t key = __float_as_uint(num);
-	const bool upd = key < best;
-	prev = upd ? best : prev;
-	idx = upd ? i : idx;
-	best = upd ? key : best;
-}
-
-PT_DEV void test_sphere(const float4 g, int i, f3 o, f3 d, float a, uint32_t &best, uint32_t &prev, int &idx, uint32_t &tiny) {
-	float bHalf, disc;
-	sphere_disc(g, o, d, a, bHalf, disc);
-	candidate_update(bHalf, disc, i, best, prev, idx, tiny);
-}
-
-// Scan of one LDS-staged chunk for tables too large to unroll against (dense scenes): most spheres are
-// missed by every ray of the wave, so the sqrt/select part runs only for a group of four in which some
-// lane can hit something.  A sphere can only be hit if disc >= 0 and bHalf < 0 (then -bHalf > sqrt(disc)
-// is possible); min(disc, -bHalf) >= 0 is a superset of that, and what is skipped is no hit in the
-// reference either (disc < 0: ray.cl:78; bHalf >= 0: t <= 0).  count4 is a multiple of 4; the chunk is
-// padded with spheres of r^2 = -inf, whose disc is -inf.
-PT_DEV void scan_chunk(const float4 *buf, int count4, int base, f3 o, f3 d, float a, uint32_t &best, uint32_t &prev, int &idx, uint32_t &tiny) {
-	for(int i = 0; i < count4; i += 4) {
-		const float4 g0 = buf[i], g1 = buf[i + 1], g2 = buf[i + 2], g3 = buf[i + 3];
-		float b0, b1, b2, b3, d0, d1, d2, d3;
-		sphere_disc(g0, o, d, a, b0, d0);
-		sphere_disc(g1, o, d, a, b1, d1);
-		sphere_disc(g2, o, d, a, b2, d2);
-		sphere_disc(g3, o, d, a, b3, d3);
-		const float m0 = fminf(d0, -b0), m1 = fminf(d1, -b1), m2 = fminf(d2, -b2), m3 = fminf(d3, -b3);
-		const float m = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
-		if(__builtin_amdgcn_ballot_w64(m >= 0.0f) != 0) {
-			if(__builtin_amdgcn_ballot_w64(m0 >= 0.0f) != 0) candidate_update(b0, d0, base + i, best, prev, idx, tiny);
-			if(__builtin_amdgcn_ballot_w64(m1 >= 0.0f) != 0) candidate_update(b1, d1, base + i + 1, best, prev, idx, tiny);
-			if(__builtin_amdgcn_ballot_w64(m2 >= 0.0f) != 0) candidate_update(b2, d2, base + i + 2, best, prev, idx, tiny);
-			if(__builtin_amdgcn_ballot_w64(m3 >= 0.0f) != 0) candidate_update(b3, d3, base + i + 3, best, prev, idx, tiny);
-		}
-	}
-}
-
-// End of a scan: the single divide, and the checks that send a lane to the reference scan (`slow`).
-PT_DEV Hit finish_scan(float a, uint32_t best, uint32_t prev, int idx, uint32_t tiny, bool &slow) {
-	Hit h;
-	h.hit = best < KEY_NONE;
-	h.idx = idx;
-	const float num = __uint_as_float(best);
-	const float pnum = __uint_as_float(prev);                // +inf when there is none
-	h.t = num / a;
-	slow = tiny < PT_SQRT_TINY_BITS - 1u;
-	slow |= !(a >= 0x1p-40f && a <= 0x1p40f);
-	slow |= h.hit && (!(num >= 0x1p-80f && num <= 0x1p80f) || pnum <= num * (1.0f + 0x1p-21f));
-	return h;
-}
-
-template <typename Tab>
-PT_DEV Hit finish_hit(const Tab geom, int n, f3 o, f3 d, float a, uint32_t best, uint32_t prev, int idx, uint32_t tiny) {
-	bool slow;
-	Hit h = finish_scan(a, best, prev, idx, tiny, slow);
-	if(__builtin_expect(slow, 0)) h = closest_hit_reference(geom, n, o, d, a);
-	return h;
-}
-
-// The reference scan for ONE ray by the whole wave: lane L tests spheres L, L+64, ... with the
-// reference's own arithmetic (sqrt and divide per sphere), then a lexicographic (t, index) minimum over
-// the lanes gives the smallest rounded t at the lowest index — what ray.cl:101-110 computes serially.
-// o, d, a must be wave-uniform.  Used by the streaming kernel for lanes that ask for the exact scan and
-// whenever few lanes of a wave are tracing (the tail of a render): 64 spheres per step instead of one.
-PT_DEV Hit closest_hit_wave(const float4 *__restrict__ geom, int n, f3 o, f3 d, float a, int lane) {
-	uint32_t bk = 0x7f800000u;      // keys are bits(t) - 1; every t > 0 up to +inf is below this
-	int bi = 0;
-	for(int i = lane; i < n; i += 64) {
-		float bHalf, disc;
-		sphere_disc(geom[i], o, d, a, bHalf, disc);
-		const float t = (-bHalf - sqrtf(disc)) / a;      // disc < 0 (ray.cl:78): sqrtf gives NaN, t is NaN, no hit
-		const uint32_t key = __float_as_uint(t) - 1u;
-		if(key < bk) { bk = key; bi = i; }
-	}
-	for(int off = 32; off > 0; off >>= 1) {
-		const uint32_t ok = (uint32_t)__shfl_xor((int)bk, off, 64);
-		const int oi = __shfl_xor(bi, off, 64);
-		if(ok < bk || (ok == bk && oi < bi)) { bk = ok; bi = oi; }
-	}
-	Hit h;
-	h.hit = bk < 0x7f800000u;
-	h.t = __uint_as_float(bk + 1u);
-	h.idx = bi;
-	return h;
-}
-
-template <typename Tab>
-PT_DEV Hit closest_hit(const Tab geom, int n, f3 o, f3 d, float a) {
-	uint32_t best = KEY_NONE, prev = KEY_NONE, tiny = 0xffffffffu;
-	int idx = 0;
-	int i = 0;
-	for(; i + 3 <= n; i += 3) {
-		const float4 g0 = geom[i], g1 = geom[i + 1], g2 = geom[i + 2];
-		test_sphere(g0, i, o, d, a, best, prev, idx, tiny);
-		test_sphere(g1, i + 1, o, d, a, best, prev, idx, tiny);
-		test_sphere(g2, i + 2, o, d, a, best, prev, idx, tiny);
-	}
-	for(; i < n; i++) test_sphere(geom[i], i, o, d, a, best, prev, idx, tiny);
-	return finish_hit(geom, n, o, d, a, best, prev, idx, tiny);
-}
-
-// ---------------------------------------------------------------------------------------
-// Kernel v2 (scenes whose tables fit in LDS): one thread per pixel, all samples in-kernel,
-// lock-step sample loop, geometry and material tables staged in LDS and read back as
-// wave-uniform (geometry) or per-lane (material of the winning sphere) ds_reads, so the
-// arithmetic runs on VGPR operands at full VALU rate.
-// ---------------------------------------------------------------------------------------
-template <bool COUNT>
-__global__ __launch_bounds__(256) void pt_render_lds_kernel(float4 *__restrict__ image, const KParams p, const SceneTables sc,
-                                                             const uint64_t *__restrict__ seedmul,
-                                                             unsigned long long *__restrict__ bounceCounter) {
-	extern __shared__ float4 lds[];
-	float4 *const sGeom = lds, *const sMatA = lds + p.n, *const sMatB = lds + 2 * p.n;
-	for(int i = (int)threadIdx.x; i < p.n; i += (int)blockDim.x) {
-		sGeom[i] = sc.geom[i];
-		sMatA[i] = sc.matA[i];
-		sMatB[i] = sc.matB[i];
-	}
-	__syncthreads();
-	// Sample-interleaved lanes: a pixel is served by S = 1 << p.logS adjacent lanes, lane `sub` tracing the
-	// samples k = sub (mod S).  The samples of a pixel are independent paths (src/cl/main.cl:6: the RNG
-	// stream depends on (id, seed_k) only); what is serial is the running mean, so after every round of S
-	// samples each lane collects the S colours by shuffles and accumulates them IN ORDER k, k+1, ...
-	// (every lane of the group redundantly, a few dozen instructions).  Bit-identical to S = 1; it only
-	// multiplies the number of waves for images that cannot fill the chip on their own (a 640x360 frame,
-	// or one GPU's bands of a 1080p frame split 8 ways, is ~4000 waves for 8192 wave slots).
-	const int S = 1 << p.logS;
-	const int thread = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-	const int sub = thread & (S - 1);
-	const int groupBase = (int)(threadIdx.x & 63) & ~(S - 1);
-	const int id = pixel_id(p, thread >> p.logS);
-	unsigned int myBounces = 0;
-	if(id >= 0) {
-		const f3 origin = camera_origin(p, id);
-		f3 acc = mk3(0.0f, 0.0f, 0.0f);
-		if(p.firstFrame > 0) {
-			float4 v = image[id];
-			acc = mk3(v.x, v.y, v.z);
-		}
-		for(int k0 = 0; k0 < p.nFrames; k0 += S) {
-			const int k = k0 + sub;
-			f3 color = mk3(0.0f, 0.0f, 0.0f);                                            // ray.cl:92
-			if(k < p.nFrames) {
-				Path pt;
-				start_sample(pt, p, id, origin, seedmul[k]);
-				for(int j = 0; j < p.maxDepth; j++) {                                    // ray.cl:96
-					if(COUNT) myBounces++;
-					const float ln = len3(pt.d);
-					const float a = ln * ln;                                             // ray.cl:73 pow(length(d),2)
-					const Hit h = closest_hit(sGeom, p.n, pt.o, pt.d, a);
-					if(!h.hit) { color = mul3(pt.mask, mk3(p.bgx, p.bgy, p.bgz)); break; }   // ray.cl:112-115
-					if(shade_hit(pt, h.t, sGeom[h.idx], sMatA[h.idx], sMatB[h.idx], color)) break;
-				}
-			}
-			if(S == 1) acc = accumulate(acc, color, p, p.firstFrame + k0);
-			else {
-				const int round = p.nFrames - k0 < S ? p.nFrames - k0 : S;
-				for(int s = 0; s < round; s++) {
-					const f3 c = mk3(__shfl(color.x, groupBase + s, 64), __shfl(color.y, groupBase + s, 64), __shfl(color.z, groupBase + s, 64));
-					acc = accumulate(acc, c, p, p.firstFrame + k0 + s);
-				}
-			}
-		}
-		if(COUNT && S > 1) {
-			unsigned int v = myBounces, tot = 0;
-			for(int s = 0; s < S; s++) tot += (unsigned int)__shfl((int)v, groupBase + s, 64);
-			if(sub == 0) image[id] = make_float4(acc.x, acc.y, acc.z, (float)tot);
-		} else if(sub == 0) image[id] = make_float4(acc.x, acc.y, acc.z, COUNT ? (float)myBounces : 0.0f);
-	}
-	if(COUNT) {
-		unsigned int v = myBounces;
-		for(int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-		if((threadIdx.x & 63) == 0 && v) atomicAdd(bounceCounter, (unsigned long long)v);
-	}
-}
-
-// ---------------------------------------------------------------------------------------
-// Streaming kernel (tables that do not fit in LDS: BASELINE config 3, 10^4-10^5 spheres).
-// One wave per block, persistent: waves pull pixels from a device-wide queue until it is empty.
-//  * A lane owns ONE pixel at a time and runs its samples in order k = 0, 1, ... (the running mean
-//    of src/cl/main.cl:29 is a serial chain per pixel), but the moment a path ends the lane starts
-//    its next sample, and the moment a pixel is finished the lane takes the next pixel from the
-//    queue: the idle lanes are balloted, ONE atomicAdd per wave reserves as many pixels as there are
-//    idle lanes and mbcnt hands them out.  Open scenes end paths after 1-3 bounces and the work per
-//    pixel varies several-fold across the image; lock-step lanes would idle most of the time.
-//  * Each bounce of the wave streams the geometry table through a double-buffered, wave-private LDS
-//    chunk (the next chunk's global load is in flight while this one is scanned by scan_chunk()):
-//    no block barriers, waves drift freely.
-// Legal because a sample's RNG stream is a pure function of (id, seed_k) (src/cl/main.cl:6).
-// ---------------------------------------------------------------------------------------
-#define PT_CHUNK 128
-#define PT_COOP_MAX_LANES 16   // at or below this many tracing lanes the wave scans ray by ray, 64 spheres per step
-#define PT_PAD_SPHERE make_float4(0.0f, 0.0f, 0.0f, -__builtin_inff())   // r^2 = -inf: disc = -inf, never a candidate
-
-template <bool COUNT>
-__global__ __launch_bounds__(64) void pt_render_stream_kernel(float4 *__restrict__ image, const KParams p, const SceneTables sc,
-                                                               const uint64_t *__restrict__ seedmul,
-                                                               unsigned long long *__restrict__ bounceCounter,
-                                                               unsigned int *__restrict__ queue) {
-	__shared__ float4 sChunk[2][PT_CHUNK];
-	const int lane = (int)threadIdx.x;
-	const int nchunks = (p.n + PT_CHUNK - 1) / PT_CHUNK;
-	unsigned int myBounces = 0;
-	unsigned int pixelStart = 0;
-	bool has = false;          // this lane owns a pixel
-	bool exhausted = false;    // wave-uniform: the queue has no more pixels
-	int id = 0, k = 0, j = 0;
-	Path pt;
-	pt.o = pt.d = pt.mask = mk3(0.0f, 0.0f, 0.0f);
-	pt.rng = 0;
-	f3 origin = mk3(0.0f, 0.0f, 0.0f), acc = mk3(0.0f, 0.0f, 0.0f);
-	for(;;) {
-		// ---- refill: idle lanes take the next pixels of the queue
-		const unsigned long long idle = __builtin_amdgcn_ballot_w64(!has);
-		if(idle != 0 && !exhausted) {
-			const unsigned int cnt = (unsigned int)__popcll(idle);
-			unsigned int base = 0;
-			if(lane == __ffsll((long long)idle) - 1) base = atomicAdd(queue, cnt);
-			base = (unsigned int)__builtin_amdgcn_readlane((int)base, __ffsll((long long)idle) - 1);
-			exhausted = base + cnt >= (unsigned int)p.localPixels;
-			if(!has) {
-				const unsigned int below = __builtin_amdgcn_mbcnt_hi((unsigned int)(idle >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)idle, 0u));
-				const unsigned int t = base + below;
-				const int nid = t < (unsigned int)p.localPixels ? pixel_id(p, (int)t) : -1;
-				if(nid >= 0) {
-					has = true;
-					pixelStart = myBounces;
-					id = nid; k = 0; j = 0;
-					origin = camera_origin(p, id);
-					acc = mk3(0.0f, 0.0f, 0.0f);
-					if(p.firstFrame > 0) {
-						float4 v = image[id];
-						acc = mk3(v.x, v.y, v.z);
-					}
-					start_sample(pt, p, id, origin, seedmul[0]);
-				}
-			}
-		}
-		if(__builtin_amdgcn_ballot_w64(has) == 0) {
-			if(exhausted) break;
-			continue;      // every pixel this wave just drew was out of range: draw again
-		}
-		// ---- one bounce of every lane that owns a pixel
-		const bool tracing = has && j < p.maxDepth;                                      // ray.cl:96
-		float a = 1.0f;
-		if(tracing) {
-			if(COUNT) myBounces++;
-			const float ln = len3(pt.d);
-			a = ln * ln;                                                                 // ray.cl:73
-		}
-		Hit h;
-		h.hit = false; h.t = 0.0f; h.idx = 0;
-		const unsigned long long tmask = __builtin_amdgcn_ballot_w64(tracing);
-		unsigned long long coop = tmask;      // lanes whose ray the whole wave scans together
-		if(__popcll(tmask) > PT_COOP_MAX_LANES) {
-			// ray-parallel: every lane scans the whole table for its own ray
-			uint32_t best = KEY_NONE, prev = KEY_NONE, tiny = 0xffffffffu;
-			int idx = 0;
-			sChunk[0][lane] = lane < p.n ? sc.geom[lane] : PT_PAD_SPHERE;
-			sChunk[0][lane + 64] = lane + 64 < p.n ? sc.geom[lane + 64] : PT_PAD_SPHERE;
-			__syncthreads();
-			for(int c = 0; c < nchunks; c++) {
-				float4 r0 = PT_PAD_SPHERE, r1 = PT_PAD_SPHERE;
-				const bool more = c + 1 < nchunks;
-				if(more) {
-					const int i0 = (c + 1) * PT_CHUNK + lane, i1 = i0 + 64;
-					if(i0 < p.n) r0 = sc.geom[i0];
-					if(i1 < p.n) r1 = sc.geom[i1];
-				}
-				if(tracing) {
-					const int left = p.n - c * PT_CHUNK;
-					const int count4 = left >= PT_CHUNK ? PT_CHUNK : ((left + 3) & ~3);
-					scan_chunk(sChunk[c & 1], count4, c * PT_CHUNK, pt.o, pt.d, a, best, prev, idx, tiny);
-				}
-				if(more) {
-					sChunk[(c + 1) & 1][lane] = r0;
-					sChunk[(c + 1) & 1][lane + 64] = r1;
-				}
-				__syncthreads();
-			}
-			bool slow = false;
-			if(tracing) h = finish_scan(a, best, prev, idx, tiny, slow);
-			coop = __builtin_amdgcn_ballot_w64(slow);
-		}
-		// sphere-parallel: the wave takes the remaining rays one at a time, with the reference's arithmetic
-		while(coop != 0) {
-			const int L = __ffsll((long long)coop) - 1;
-			coop &= coop - 1;
-			const f3 ro = mk3(__shfl(pt.o.x, L, 64), __shfl(pt.o.y, L, 64), __shfl(pt.o.z, L, 64));
-			const f3 rd = mk3(__shfl(pt.d.x, L, 64), __shfl(pt.d.y, L, 64), __shfl(pt.d.z, L, 64));
-			const float ra = __shfl(a, L, 64);
-			const Hit hw = closest_hit_wave(sc.geom, p.n, ro, rd, ra, lane);
-			if(lane == L) h = hw;
-		}
-		bool ended = false;
-		f3 color = mk3(0.0f, 0.0f, 0.0f);                                                // ray.cl:92,174
-		if(tracing) {
-			if(!h.hit) { color = mul3(pt.mask, mk3(p.bgx, p.bgy, p.bgz)); ended = true; }   // ray.cl:112-115
-			else ended = shade_hit(pt, h.t, sc.geom[h.idx], sc.matA[h.idx], sc.matB[h.idx], color);
-			j++;
-		}
-		if(has && !ended && j >= p.maxDepth) ended = true;                               // loop exhausted: black
-		if(ended) {
-			acc = accumulate(acc, color, p, p.firstFrame + k);
-			k++;
-			j = 0;
-			if(k < p.nFrames) start_sample(pt, p, id, origin, seedmul[k]);
-			else {
-				image[id] = make_float4(acc.x, acc.y, acc.z, COUNT ? (float)(myBounces - pixelStart) : 0.0f);
-				has = false;
-			}
-		}
-	}
-	if(COUNT) {
-		unsigned int v = myBounces;
-		for(int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-		if(lane == 0 && v) atomicAdd(bounceCounter, (unsigned long long)v);
-	}
-}
 
 // ---------------------------------------------------------------------------------------
 // Epilogue: gamma (sqrt), clamp, (int)(x*255) truncation -> packed RGB8
@@ -864,23 +290,27 @@ extern "C" int pt_render(pt_ctx *c, const pt_render_args *a) {
 		else while(want < 3 && (lp << want) < 64ll * 12 * 8192 && (2 << want) <= a->n_frames) want++;
 		p.logS = want;
 	}
-	dim3 block(256), grid((unsigned)(((lp << p.logS) + 255) / 256));
+	LaunchArgs la;
+	la.image = img; la.p = p; la.sc = sc; la.seedmul = c->seedmul; la.bounceCounter = c->counter; la.queue = c->queue;
+	la.stream = st; la.count = a->bounce_count != NULL;
+	la.gridPixels = (unsigned)(((lp << p.logS) + 255) / 256);
 	// tables of up to PT_LDS_MAX_SPHERES spheres (48 B each) are staged whole in LDS
 	const char *force = getenv("PT_KERNEL");      // debugging aid: "v1" forces the first, scalar-load kernel
-	const bool useV1 = force && strcmp(force, "v1") == 0;
-	const bool useLds = !useV1 && c->nSpheres <= PT_LDS_MAX_SPHERES;
-	const size_t ldsBytes = useLds ? 3 * sizeof(float4) * (size_t)c->nSpheres : 0;
+	la.kernel = force && strcmp(force, "v1") == 0 ? PT_K_V1 : c->nSpheres <= PT_LDS_MAX_SPHERES ? PT_K_LDS : PT_K_STREAM;
+	la.ldsBytes = la.kernel == PT_K_LDS ? 3 * sizeof(float4) * (size_t)c->nSpheres : 0;
 	// streaming kernel: persistent one-wave blocks, at most 32 per CU; surplus pixels come through the queue
 	const long long swaves = (lp + 63) / 64;
-	dim3 sgrid((unsigned)(swaves < 256 * 32 ? swaves : 256 * 32));
+	la.gridStream = (unsigned)(swaves < 256 * 32 ? swaves : 256 * 32);
+	// float rules: strict (bit-identical to the oracle) unless the caller, or PT_MATH=fast, asks for the relaxed build
+	bool fast = a->fast_math != 0;
+	const char *math = getenv("PT_MATH");
+	if(math && strcmp(math, "fast") == 0) fast = true;
+	if(math && strcmp(math, "strict") == 0) fast = false;
+
+	if(la.kernel == PT_K_STREAM) HIP_TRY(hipMemsetAsync(c->queue, 0, 256, st));     // before the start event: not kernel time
 	if(a->bounce_count) {
 		HIP_TRY(hipMemsetAsync(c->counter, 0, sizeof(unsigned long long), st));
-		if(useLds) hipLaunchKernelGGL(pt_render_lds_kernel<true>, grid, block, ldsBytes, st, img, p, sc, c->seedmul, c->counter);
-		else if(useV1) hipLaunchKernelGGL(pt_render_kernel<true>, grid, block, 0, st, img, p, sc, c->seedmul, c->counter);
-		else {
-			HIP_TRY(hipMemsetAsync(c->queue, 0, 256, st));
-			hipLaunchKernelGGL(pt_render_stream_kernel<true>, sgrid, dim3(64), 0, st, img, p, sc, c->seedmul, c->counter, c->queue);
-		}
+		if(fast) pt_fast::launch_render(la); else pt_strict::launch_render(la);
 		HIP_TRY(hipGetLastError());
 		unsigned long long v = 0;
 		HIP_TRY(hipMemcpyAsync(&v, c->counter, sizeof v, hipMemcpyDeviceToHost, st));
@@ -891,13 +321,9 @@ extern "C" int pt_render(pt_ctx *c, const pt_render_args *a) {
 	const bool ringTimed = a->record_timing && !a->kernel_ms;
 	if(ringTimed && c->nTimed >= PT_TIMING_SLOTS)
 		return fail(PT_E_STATE, "pt_render: timing ring full (call pt_kernel_times)%s", NULL);
-	const bool useStream = !useLds && !useV1;
-	if(useStream) HIP_TRY(hipMemsetAsync(c->queue, 0, 256, st));     // before the start event: not kernel time
 	if(a->kernel_ms) HIP_TRY(hipEventRecord(c->evStart, st));
 	if(ringTimed) HIP_TRY(hipEventRecord(c->ring[2 * c->nTimed], st));
-	if(useLds) hipLaunchKernelGGL(pt_render_lds_kernel<false>, grid, block, ldsBytes, st, img, p, sc, c->seedmul, c->counter);
-	else if(useV1) hipLaunchKernelGGL(pt_render_kernel<false>, grid, block, 0, st, img, p, sc, c->seedmul, c->counter);
-	else hipLaunchKernelGGL(pt_render_stream_kernel<false>, sgrid, dim3(64), 0, st, img, p, sc, c->seedmul, c->counter, c->queue);
+	if(fast) pt_fast::launch_render(la); else pt_strict::launch_render(la);
 	HIP_TRY(hipGetLastError());
 	if(ringTimed) { HIP_TRY(hipEventRecord(c->ring[2 * c->nTimed + 1], st)); c->nTimed++; }
 	if(a->kernel_ms) {

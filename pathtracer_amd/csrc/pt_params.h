@@ -1,0 +1,53 @@
+// pt_params.h — plain structs shared by the host side of the C ABI (pt_kernels.hip) and the two builds of
+// the render kernels (pt_render_kernels.h compiled as pt_strict in pt_kernels.hip and as pt_fast in
+// pt_kernels_fast.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+// ---------------------------------------------------------------------------------------
+// Kernel parameters (by value: land in SGPRs — the reference passes its three structs by
+// value too, src/c/renderer.c:160-162)
+// ---------------------------------------------------------------------------------------
+#define PT_LDS_MAX_SPHERES 512   // 24 KB of LDS per 256-thread block: 6 blocks = 24 waves per CU still fit
+
+struct KParams {
+	int W, H, maxDepth, n;
+	float bgx, bgy, bgz;
+	float px, py, pz;                   // Camera.pos
+	float cosRx, sinRx, cosRy, sinRy;   // cosf/sinf of Camera.rot.x / .y, folded on the host (rot.z is dead, src/cl/ray.cl:42-43)
+	float sensorWidth, focalLength, aperture, exposure;
+	int firstFrame, nFrames;
+	int rank, world, bandRows;          // row-band partition (pt_hip.h)
+	int localPixels;                    // pixels of this rank
+	int logS;                           // LDS kernel: 2^logS lanes share a pixel (sample-interleaved)
+};
+
+// Device scene tables (SoA).  geom[i] = {cx, cy, cz, r*r}; matA[i] = {colr, colg, colb, type bits};
+// matB[i] = {tint, fuzz, refIdx, 0}.
+struct SceneTables {
+	const float4 *geom;
+	const float4 *matA;
+	const float4 *matB;
+};
+
+
+// One render launch, as pt_render() hands it to a kernel build.
+struct LaunchArgs {
+	float4 *image;
+	KParams p;
+	SceneTables sc;
+	const uint64_t *seedmul;
+	unsigned long long *bounceCounter;
+	unsigned int *queue;          // zeroed by the caller when `kernel` is the streaming kernel
+	hipStream_t stream;
+	bool count;                   // the COUNT variants: bounce-loop iterations, per pixel and in total
+	int kernel;                   // PT_K_*
+	unsigned gridPixels;          // blocks of 256 threads over localPixels << logS
+	unsigned gridStream;          // one-wave blocks of the streaming kernel
+	size_t ldsBytes;
+};
+enum { PT_K_LDS = 0, PT_K_STREAM = 1, PT_K_V1 = 2 };
+
+namespace pt_strict { void launch_render(const LaunchArgs &la); }
+namespace pt_fast { void launch_render(const LaunchArgs &la); }

@@ -33,6 +33,7 @@ class RenderArgs(C.Structure):
         ("async_", C.c_int),
         ("kernel_ms", C.POINTER(C.c_float)),
         ("record_timing", C.c_int),
+        ("fast_math", C.c_int),
     ]
 
 
@@ -112,7 +113,7 @@ class Context:
         _check(self.lib.pt_scene_upload(self.h, sp.ctypes.data_as(C.POINTER(C.c_float)), sp.shape[0]), "pt_scene_upload")
 
     def render(self, scene, width, height, max_depth, seeds, first_frame=0, rank=0, world=1, band_rows=16,
-               d_image=None, stream=None, count_bounces=False, async_=False, time_kernel=False, record_timing=False):
+               d_image=None, stream=None, count_bounces=False, async_=False, time_kernel=False, record_timing=False, fast_math=False):
         """scene: dict with 'bg' and 'cam' (pathtracer_amd.scenes layout); the spheres must have
         been uploaded with scene_upload().  Returns the bounce count (count_bounces) or the
         HIP-event kernel time in ms (time_kernel) if asked, else None."""
@@ -136,6 +137,7 @@ class Context:
         ms = C.c_float(0)
         a.kernel_ms = C.pointer(ms) if time_kernel else None
         a.record_timing = 1 if record_timing else 0
+        a.fast_math = 1 if fast_math else 0
         _check(self.lib.pt_render(self.h, C.byref(a)), "pt_render")
         if time_kernel:
             return float(ms.value)

@@ -1,0 +1,50 @@
+"""The opt-in relaxed build (pt_render_args.fast_math / PT_MATH=fast): FMA contraction and the 1-ulp hardware sqrt
+and reciprocal — the freedoms of the reference's own build options (src/c/renderer.c:13).  Same integer RNG stream;
+the float image is NOT bit-identical: a perturbation of an ulp flips a hit/miss or reflect/refract decision about
+once per 3e5 bounces, and from there the path is a different, equally valid one.  Stated tolerance, per fixture
+(8-16 spp, where one flipped sample moves a pixel by up to 10/spp): >= 98 % of the pixels within 1e-4 of the strict
+reference image, every other pixel finite, bounce count within 0.5 %, image mean within 2 %.  Scenes without a
+decision near the perturbation (single-material micro scenes) stay within 2e-6 everywhere."""
+import os
+
+import numpy as np
+import pytest
+
+from cases import CASES
+from pathtracer_amd import hip
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_fast_math_within_stated_tolerance(ctx, name):
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    W, H, depth, spp = (int(x) for x in g["size"])
+    sc = {"spheres": g["spheres"], "bg": g["bg"], "cam": g["cam"]}
+    img, bc = hip.render_scene(ctx, sc, W, H, depth, g["seeds"], count_bounces=True, fast_math=True)
+    _, bs = hip.render_scene(ctx, sc, W, H, depth, g["seeds"], count_bounces=True)
+    rgb = img[..., :3]
+    assert np.isfinite(rgb).all() and rgb.min() >= 0
+    d = np.abs(rgb - g["strict"]).max(axis=2)
+    assert (d <= 1e-4).mean() >= 0.98, "only %.4f of the pixels within 1e-4" % (d <= 1e-4).mean()
+    assert abs(bc - bs) <= max(16, 0.005 * bs)
+    m_fast, m_ref = float(rgb.mean()), float(g["strict"].mean())
+    assert abs(m_fast - m_ref) <= 0.02 * max(m_ref, 1e-3) + 1e-6
+    if name.split("_")[0] in ("light", "lambert", "metal", "dielectric", "empty", "depth0", "depth1", "one"):
+        assert d.max() <= 2e-6
+
+
+def test_fast_math_env_switch(ctx):
+    g = np.load(os.path.join(GOLD, "frame0_64x36.npz"))
+    sc = {"spheres": g["spheres"], "bg": g["bg"], "cam": g["cam"]}
+    strict = hip.render_scene(ctx, sc, 64, 36, 50, g["seeds"])
+    fast = hip.render_scene(ctx, sc, 64, 36, 50, g["seeds"], fast_math=True)
+    assert not np.array_equal(strict, fast)
+    try:
+        os.environ["PT_MATH"] = "fast"
+        assert np.array_equal(hip.render_scene(ctx, sc, 64, 36, 50, g["seeds"]), fast)
+        os.environ["PT_MATH"] = "strict"
+        assert np.array_equal(hip.render_scene(ctx, sc, 64, 36, 50, g["seeds"], fast_math=True), strict)
+    finally:
+        os.environ.pop("PT_MATH", None)

@@ -24,6 +24,7 @@ def main():
     W = int(a[4]) if len(a) > 4 else 1920
     H = int(a[5]) if len(a) > 5 else 1080
     world = int(a[6]) if len(a) > 6 else 1       # render only rank 0's bands of a `world`-way split
+    fast = os.environ.get("PT_MATH") == "fast"
     sc = SCENES[name]()
     s = seedmod.glibc_rand_stream(spp)
     ctx = hip.Context(0)
