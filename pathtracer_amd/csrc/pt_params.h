@@ -9,7 +9,8 @@
 // Kernel parameters (by value: land in SGPRs — the reference passes its three structs by
 // value too, src/c/renderer.c:160-162)
 // ---------------------------------------------------------------------------------------
-#define PT_LDS_MAX_SPHERES 512   // 24 KB of LDS per 256-thread block: 6 blocks = 24 waves per CU still fit
+#define PT_LDS_MAX_SPHERES 512       // what the lock-step kernel can hold: 24 KB of LDS per 256-thread block (PT_KERNEL=lds)
+#define PT_LOCKSTEP_MAX_SPHERES 16   // what it is chosen for (pt_render)
 
 struct KParams {
 	int W, H, maxDepth, n;

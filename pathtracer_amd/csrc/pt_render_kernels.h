@@ -471,6 +471,11 @@ __global__ __launch_bounds__(64) void pt_render_stream_kernel(float4 *__restrict
 	pt.o = pt.d = pt.mask = mk3(0.0f, 0.0f, 0.0f);
 	pt.rng = 0;
 	f3 origin = mk3(0.0f, 0.0f, 0.0f), acc = mk3(0.0f, 0.0f, 0.0f);
+	if(nchunks == 1) {
+		sChunk[0][lane] = lane < p.n ? sc.geom[lane] : PT_PAD_SPHERE;
+		sChunk[0][lane + 64] = lane + 64 < p.n ? sc.geom[lane + 64] : PT_PAD_SPHERE;
+		__syncthreads();
+	}
 	for(;;) {
 		// ---- refill: idle lanes take the next pixels of the queue
 		const unsigned long long idle = __builtin_amdgcn_ballot_w64(!has);
@@ -518,9 +523,11 @@ __global__ __launch_bounds__(64) void pt_render_stream_kernel(float4 *__restrict
 			// ray-parallel: every lane scans the whole table for its own ray
 			uint32_t best = KEY_NONE, prev = KEY_NONE, tiny = 0xffffffffu;
 			int idx = 0;
-			sChunk[0][lane] = lane < p.n ? sc.geom[lane] : PT_PAD_SPHERE;
-			sChunk[0][lane + 64] = lane + 64 < p.n ? sc.geom[lane + 64] : PT_PAD_SPHERE;
-			__syncthreads();
+			if(nchunks > 1) {      // a table of one chunk was staged once, before the loop
+				sChunk[0][lane] = lane < p.n ? sc.geom[lane] : PT_PAD_SPHERE;
+				sChunk[0][lane + 64] = lane + 64 < p.n ? sc.geom[lane + 64] : PT_PAD_SPHERE;
+				__syncthreads();
+			}
 			for(int c = 0; c < nchunks; c++) {
 				float4 r0 = PT_PAD_SPHERE, r1 = PT_PAD_SPHERE;
 				const bool more = c + 1 < nchunks;
@@ -538,7 +545,7 @@ __global__ __launch_bounds__(64) void pt_render_stream_kernel(float4 *__restrict
 					sChunk[(c + 1) & 1][lane] = r0;
 					sChunk[(c + 1) & 1][lane + 64] = r1;
 				}
-				__syncthreads();
+				if(nchunks > 1) __syncthreads();
 			}
 			bool slow = false;
 			if(tracing) h = finish_scan(a, best, prev, idx, tiny, slow);

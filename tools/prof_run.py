@@ -12,6 +12,8 @@ SCENES = {
     "dense10k": lambda: scenes.dense_random(10000),
     "dense100k": lambda: scenes.dense_random(100000),
     "dense1k": lambda: scenes.dense_random(1000),
+    "dense500": lambda: scenes.dense_random(500),
+    "dense100": lambda: scenes.dense_random(100),
 }
 
 
