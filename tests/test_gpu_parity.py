@@ -208,3 +208,79 @@ def test_full_size_properties(ctx, oracle):
     assert np.array_equal(bits(ctx.image_read()[..., :3]), bits(img[..., :3]))
     u8 = ctx.image_read_u8()
     assert np.array_equal(u8[540], oracle.postprocess(img[540]))
+
+
+def test_streaming_kernel_composes_and_partitions(ctx, oracle):
+    """The persistent streaming kernel (tables above 16 spheres): continued accumulators, row-band partitions and
+    the bounce count behave as on the lock-step kernel."""
+    g = np.load(os.path.join(GOLD, "dense500_96x54.npz"))
+    sc = {"spheres": g["spheres"], "bg": g["bg"], "cam": g["cam"]}
+    s = seedmod.glibc_rand_stream(7)
+    full, bc = hip.render_scene(ctx, sc, 96, 54, 50, s, count_bounces=True)
+    want, wb = oracle.render(sc, 96, 54, 50, s, count_bounces=True)
+    assert np.array_equal(bits(full[..., :3]), bits(want[..., :3])) and bc == wb
+    ctx.image_alloc(96, 54)
+    ctx.render(sc, 96, 54, 50, s[:2])
+    ctx.render(sc, 96, 54, 50, s[2:3], first_frame=2)
+    ctx.render(sc, 96, 54, 50, s[3:], first_frame=3)
+    assert np.array_equal(bits(ctx.image_read()[..., :3]), bits(full[..., :3]))
+    for world, band in ((2, 8), (5, 3), (8, 100)):
+        ctx.image_alloc(96, 54)
+        for r in range(world):
+            ctx.render(sc, 96, 54, 50, s, rank=r, world=world, band_rows=band)
+        assert np.array_equal(bits(ctx.image_read()[..., :3]), bits(full[..., :3])), (world, band)
+
+
+@pytest.mark.parametrize("n,W,H,spp", [(10000, 64, 36, 2), (100000, 32, 18, 1)])
+def test_config3_dense_tables_match_oracle(ctx, oracle, n, W, H, spp):
+    """BASELINE config 3 table sizes (10^4 and 10^5 random spheres) at an image the oracle finishes in seconds."""
+    sc = scenes.dense_random(n)
+    s = seedmod.glibc_rand_stream(spp)
+    img, bc = hip.render_scene(ctx, sc, W, H, 50, s, count_bounces=True)
+    want, wb = oracle.render(sc, W, H, 50, s, count_bounces=True)
+    assert np.array_equal(bits(img[..., :3]), bits(want[..., :3])), mismatch_report(img[..., :3], want[..., :3])
+    assert bc == wb and img[..., :3].max() > 0
+
+
+def test_config3_full_size_rows(ctx, oracle):
+    """1920x1080 over 10^4 spheres at 1 spp: sampled rows against the oracle, partition invariance."""
+    sc = scenes.dense_random(10000)
+    W, H = 1920, 1080
+    s = seedmod.glibc_rand_stream(1)
+    img = hip.render_scene(ctx, sc, W, H, 50, s)
+    for r in (0, 541, 1079):
+        want = oracle.render(sc, W, H, 50, s, id_begin=r * W, id_end=r * W + 480)
+        assert np.array_equal(bits(img[r, :480, :3]), bits(want[r, :480, :3])), "row %d" % r
+    ctx.image_alloc(W, H)
+    for r in range(4):
+        ctx.render(sc, W, H, 50, s, rank=r, world=4, band_rows=8)
+    assert np.array_equal(bits(ctx.image_read()), bits(img))
+
+
+def test_config4_4k_rows_and_partition(ctx, oracle):
+    """BASELINE config 4 size (3840x2160, frame-0 scene) at 2 spp: sampled rows against the oracle bit for bit,
+    and the 8-rank band partition reassembles the single-GPU image."""
+    sc = scenes.main_lua_frame(0)
+    W, H = 3840, 2160
+    s = seedmod.glibc_rand_stream(2)
+    img = hip.render_scene(ctx, sc, W, H, 50, s)
+    assert not np.isnan(img).any()
+    for r in (0, 1080, 2159):
+        want = oracle.render(sc, W, H, 50, s, id_begin=r * W, id_end=(r + 1) * W)
+        assert np.array_equal(bits(img[r, :, :3]), bits(want[r, :, :3])), "row %d" % r
+    ctx.image_alloc(W, H)
+    for r in range(8):
+        ctx.render(sc, W, H, 50, s, rank=r, world=8, band_rows=8)
+    assert np.array_equal(bits(ctx.image_read()), bits(img))
+
+
+def test_config5_lattice_full_size_rows(ctx, oracle):
+    """BASELINE config 5 (glass lattice + emitters, depth 32) at 1920x1080, 2 spp: sampled rows against the oracle."""
+    sc = scenes.glass_lattice()
+    W, H = 1920, 1080
+    s = seedmod.glibc_rand_stream(2)
+    img, bc = hip.render_scene(ctx, sc, W, H, 32, s, count_bounces=True)
+    for r in (3, 540, 900):
+        want = oracle.render(sc, W, H, 32, s, id_begin=r * W, id_end=(r + 1) * W)
+        assert np.array_equal(bits(img[r, :, :3]), bits(want[r, :, :3])), "row %d" % r
+    assert 20.0 < bc / (W * H * 2) < 32.0
