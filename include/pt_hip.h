@@ -128,7 +128,8 @@ int pt_image_read_u8(pt_ctx *ctx, const void *d_image, int width, int height, un
  *   op 3: in_f[2i]=x, in_f[2i+1]=y: x/y, sqrt(x), reflectance(x,y), pow5(x) -> out_f[4i..]
  *   op 4: float bit patterns a[i] .. a[i]+b[i]-1: out_u64[i] = (#patterns where the kernels' short
  *         correctly-rounded sqrt differs from sqrtf inside its stated domain) << 32
- *         | #patterns where their guarded sqrt differs from sqrtf anywhere */
+ *         | #patterns where their guarded sqrt differs from sqrtf anywhere
+ *   op 5: same ranges: out_u64[i] = #patterns where the kernels' short reciprocal differs from 1.0f / x */
 int pt_selftest(pt_ctx *ctx, int op, const uint64_t *a, const uint64_t *b, const float *in_f,
                 int n, uint64_t *out_u64, float *out_f);
 

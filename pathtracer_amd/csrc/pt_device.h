@@ -70,7 +70,22 @@ PT_DEV float sqrt_cr(float x) {
 }
 
 PT_DEV float len3(f3 a) { return sqrt_cr(dot3(a, a)); }
-PT_DEV f3 norm3(f3 a) { float inv = pt_div(1.0f, len3(a)); return scl3(a, inv); }
+
+// 1.0f / x for the normalisations: v_rcp_f32 (1 ulp) and two FMA Newton steps, which land on the correctly
+// rounded quotient for every x with 2^-126 <= |x| <= 2^126 (pt_selftest op 5 checks all of them against the
+// compiler's correctly rounded divide); outside (0, denormals, huge, inf, NaN) the full divide is used.
+PT_DEV float rcp_cr(float x) {
+#if PT_FAST_MATH
+	return __builtin_amdgcn_rcpf(x);
+#endif
+	float r = __builtin_amdgcn_rcpf(x);
+	r = __builtin_fmaf(__builtin_fmaf(-x, r, 1.0f), r, r);
+	r = __builtin_fmaf(__builtin_fmaf(-x, r, 1.0f), r, r);
+	if(__builtin_expect((__float_as_uint(x) & 0x7fffffffu) - 0x00800000u > 0x7e800000u - 0x00800000u, 0)) r = 1.0f / x;
+	return r;
+}
+
+PT_DEV f3 norm3(f3 a) { float inv = rcp_cr(len3(a)); return scl3(a, inv); }
 
 constexpr uint32_t PT_M31 = 2147483647u;   // MINSTD modulus 2^31 - 1 (src/cl/rng.cl:12)
 

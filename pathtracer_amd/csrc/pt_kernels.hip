@@ -82,6 +82,15 @@ __global__ void pt_selftest_kernel(int op, const uint64_t *a, const uint64_t *b,
 			if(dom && (nanw ? (g2 == g2) : (__float_as_uint(g2) != __float_as_uint(want)))) bad_nt++;
 		}
 		ou[i] = bad_cr + (bad_nt << 32);
+	} else if(op == 5) {
+		// bit patterns a[i] .. a[i] + b[i] - 1: how many have rcp_cr(x) != 1.0f / x (NaN == NaN)
+		uint64_t bad = 0;
+		for(uint64_t k = 0; k < b[i]; k++) {
+			const float x = __uint_as_float((uint32_t)(a[i] + k));
+			const float want = 1.0f / x, got = rcp_cr(x);
+			if(want != want ? (got == got) : (__float_as_uint(got) != __float_as_uint(want))) bad++;
+		}
+		ou[i] = bad;
 	}
 }
 
@@ -396,7 +405,7 @@ extern "C" int pt_image_read_u8(pt_ctx *c, const void *d_image, int width, int h
 
 extern "C" int pt_selftest(pt_ctx *c, int op, const uint64_t *a, const uint64_t *b, const float *in_f, int n,
                            uint64_t *out_u64, float *out_f) {
-	if(!c || n <= 0 || op < 0 || op > 4) return fail(PT_E_INVALID, "pt_selftest: bad arguments%s", NULL);
+	if(!c || n <= 0 || op < 0 || op > 5) return fail(PT_E_INVALID, "pt_selftest: bad arguments%s", NULL);
 	HIP_TRY(hipSetDevice(c->device));
 	uint64_t *da = NULL, *db = NULL, *dou = NULL;
 	float *dif = NULL, *dof = NULL;

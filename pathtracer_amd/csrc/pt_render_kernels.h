@@ -216,8 +216,8 @@ PT_DEV Hit closest_hit_reference(const Tab geom, int n, f3 o, f3 d, float a) {
 // Branch-free scan with ONE divide per ray instead of one per candidate.  Same result as
 // closest_hit_reference for every input; the argument:
 //  * num_i = -bHalf_i - sqrt(disc_i) is computed exactly as the reference does (sqrt_nt == sqrtf
-//    unless 0 < |disc| < 2^-96; the scan keeps the smallest non-zero |disc| and raises `slow` below
-//    that).  A negative or NaN disc gives a NaN num.
+//    unless 0 < |disc| < 2^-96; the scan keeps the smallest |disc| and raises `slow` below that).
+//    A negative or NaN disc gives a NaN num.
 //  * With 2^-40 <= a <= 2^40 and 2^-80 <= num <= 2^80 the quotient t = num/a neither underflows nor
 //    overflows, so t > 0 <=> num > 0, and rounding is monotonic: num_i < num_j => t_i <= t_j.
 //    A NaN or non-positive num is no hit on both sides.  Outside those ranges: `slow`.
@@ -241,7 +241,7 @@ PT_DEV void sphere_disc(const float4 g, f3 o, f3 d, float a, float &bHalf, float
 	disc = bHalf * bHalf - a * c;
 }
 
-PT_DEV void candidate_update(float bHalf, float disc, int i, uint32_t &best, uint32_t &prev, int &idx, uint32_t &tiny) {
+PT_DEV void candidate_update(float bHalf, float disc, int i, uint32_t &best, uint32_t &prev, int &idx, float &tiny) {
 #if PT_FAST_MATH
 	// relaxed build: no tie or small-disc bookkeeping; num == +0 (t == 0, no hit) is kept out by the -1
 	const float numf = -bHalf - __builtin_amdgcn_sqrtf(disc);
@@ -251,7 +251,9 @@ PT_DEV void candidate_update(float bHalf, float disc, int i, uint32_t &best, uin
 	best = updf ? keyf : best;
 	return;
 #endif
-	tiny = min(tiny, (__float_as_uint(disc) & 0x7fffffffu) - 1u);   // smallest non-zero |disc| seen (zero wraps to the top)
+	// smallest |disc| seen, as one v_min_f32 with the |x| source modifier (fminf(fabsf()) costs two extra
+	// canonicalising v_max); a NaN disc leaves it unchanged
+	asm("v_min_f32 %0, %0, |%1|" : "+v"(tiny) : "v"(disc));
 	const float num = -bHalf - sqrt_nt(disc);
 	const uint32_t key = __float_as_uint(num);
 	const bool upd = key < best;
@@ -260,7 +262,7 @@ PT_DEV void candidate_update(float bHalf, float disc, int i, uint32_t &best, uin
 	best = upd ? key : best;
 }
 
-PT_DEV void test_sphere(const float4 g, int i, f3 o, f3 d, float a, uint32_t &best, uint32_t &prev, int &idx, uint32_t &tiny) {
+PT_DEV void test_sphere(const float4 g, int i, f3 o, f3 d, float a, uint32_t &best, uint32_t &prev, int &idx, float &tiny) {
 	float bHalf, disc;
 	sphere_disc(g, o, d, a, bHalf, disc);
 	candidate_update(bHalf, disc, i, best, prev, idx, tiny);
@@ -272,7 +274,7 @@ PT_DEV void test_sphere(const float4 g, int i, f3 o, f3 d, float a, uint32_t &be
 // is possible); min(disc, -bHalf) >= 0 is a superset of that, and what is skipped is no hit in the
 // reference either (disc < 0: ray.cl:78; bHalf >= 0: t <= 0).  count4 is a multiple of 4; the chunk is
 // padded with spheres of r^2 = -inf, whose disc is -inf.
-PT_DEV void scan_chunk(const float4 *buf, int count4, int base, f3 o, f3 d, float a, uint32_t &best, uint32_t &prev, int &idx, uint32_t &tiny) {
+PT_DEV void scan_chunk(const float4 *buf, int count4, int base, f3 o, f3 d, float a, uint32_t &best, uint32_t &prev, int &idx, float &tiny) {
 	for(int i = 0; i < count4; i += 4) {
 		const float4 g0 = buf[i], g1 = buf[i + 1], g2 = buf[i + 2], g3 = buf[i + 3];
 		float b0, b1, b2, b3, d0, d1, d2, d3;
@@ -292,7 +294,7 @@ PT_DEV void scan_chunk(const float4 *buf, int count4, int base, f3 o, f3 d, floa
 }
 
 // End of a scan: the single divide, and the checks that send a lane to the reference scan (`slow`).
-PT_DEV Hit finish_scan(float a, uint32_t best, uint32_t prev, int idx, uint32_t tiny, bool &slow) {
+PT_DEV Hit finish_scan(float a, uint32_t best, uint32_t prev, int idx, float tiny, bool &slow) {
 	Hit h;
 	h.hit = best < KEY_NONE;
 	h.idx = idx;
@@ -305,14 +307,14 @@ PT_DEV Hit finish_scan(float a, uint32_t best, uint32_t prev, int idx, uint32_t 
 	const float num = __uint_as_float(best);
 	const float pnum = __uint_as_float(prev);                // +inf when there is none
 	h.t = num / a;
-	slow = tiny < PT_SQRT_TINY_BITS - 1u;
+	slow = tiny < 0x1p-96f;      // some |disc| below sqrt_nt's domain (an exactly zero disc lands here too: rare, and exact either way)
 	slow |= !(a >= 0x1p-40f && a <= 0x1p40f);
 	slow |= h.hit && (!(num >= 0x1p-80f && num <= 0x1p80f) || pnum <= num * (1.0f + 0x1p-21f));
 	return h;
 }
 
 template <typename Tab>
-PT_DEV Hit finish_hit(const Tab geom, int n, f3 o, f3 d, float a, uint32_t best, uint32_t prev, int idx, uint32_t tiny) {
+PT_DEV Hit finish_hit(const Tab geom, int n, f3 o, f3 d, float a, uint32_t best, uint32_t prev, int idx, float tiny) {
 	bool slow;
 	Hit h = finish_scan(a, best, prev, idx, tiny, slow);
 	if(__builtin_expect(slow, 0)) h = closest_hit_reference(geom, n, o, d, a);
@@ -348,7 +350,8 @@ PT_DEV Hit closest_hit_wave(const float4 *__restrict__ geom, int n, f3 o, f3 d, 
 
 template <typename Tab>
 PT_DEV Hit closest_hit(const Tab geom, int n, f3 o, f3 d, float a) {
-	uint32_t best = KEY_NONE, prev = KEY_NONE, tiny = 0xffffffffu;
+	uint32_t best = KEY_NONE, prev = KEY_NONE;
+	float tiny = __builtin_inff();
 	int idx = 0;
 	int i = 0;
 	for(; i + 3 <= n; i += 3) {
@@ -521,7 +524,8 @@ __global__ __launch_bounds__(64) void pt_render_stream_kernel(float4 *__restrict
 		unsigned long long coop = tmask;      // lanes whose ray the whole wave scans together
 		if(__popcll(tmask) > PT_COOP_MAX_LANES) {
 			// ray-parallel: every lane scans the whole table for its own ray
-			uint32_t best = KEY_NONE, prev = KEY_NONE, tiny = 0xffffffffu;
+			uint32_t best = KEY_NONE, prev = KEY_NONE;
+			float tiny = __builtin_inff();
 			int idx = 0;
 			if(nchunks > 1) {      // a table of one chunk was staged once, before the loop
 				sChunk[0][lane] = lane < p.n ? sc.geom[lane] : PT_PAD_SPHERE;

@@ -81,6 +81,16 @@ def test_short_sqrt_is_sqrtf_on_every_float(ctx):
     assert int((ou >> np.uint64(32)).sum()) == 0, "sqrt_nt != sqrtf inside its domain"
 
 
+def test_short_reciprocal_is_the_divide_on_every_float(ctx):
+    """pt_device.h rcp_cr (v_rcp_f32 + two FMA steps, full divide outside the normal range) == 1.0f / x on all 2^32 patterns."""
+    n = 1 << 16
+    a = (np.arange(n, dtype=np.uint64) << np.uint64(16))
+    b = np.full(n, 1 << 16, np.uint64)
+    ou, _ = ctx.selftest(5, a=a, b=b)
+    bad = np.nonzero(ou)[0]
+    assert len(bad) == 0, "rcp_cr != 1/x in %d chunks, first at bits 0x%08x" % (len(bad), int(bad[0]) << 16)
+
+
 def test_kernel_timing_ring(ctx):
     sc = scenes.main_lua_frame(0)
     ctx.scene_upload(sc["spheres"])
