@@ -295,7 +295,7 @@ extern "C" int pt_render(pt_ctx *c, const pt_render_args *a) {
 	{
 		const char *fs = getenv("PT_LANES_PER_PIXEL");      // debugging aid: force 1, 2, 4 or 8
 		int want = 0;
-		if(fs) { int v = atoi(fs); while((1 << want) < v && want < 3) want++; }
+		if(fs) { int v = atoi(fs); while((1 << want) < v && want < 5) want++; }
 		else while(want < 3 && (lp << want) < 64ll * 12 * 8192 && (2 << want) <= a->n_frames) want++;
 		p.logS = want;
 	}
