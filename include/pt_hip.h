@@ -72,6 +72,11 @@ typedef struct pt_render_args {
 	                             options (-cl-mad-enable -cl-fast-relaxed-math, src/c/renderer.c:13): FMA
 	                             contraction, 1-ulp hardware sqrt and reciprocal; same RNG stream, image within
 	                             tolerance.  The environment variable PT_MATH=fast|strict overrides this field. */
+	int accel;                /* 0 (default): the reference's linear scan over all spheres (src/cl/ray.cl:101-110).
+	                             1: opt-in extension with no reference counterpart — the same closest hit (same
+	                             arithmetic per tested sphere, lowest index on equal distance) found through a
+	                             uniform grid built from the uploaded scene; meant for 10^4-10^5 sphere tables.
+	                             The environment variable PT_ACCEL=grid|none overrides this field. */
 } pt_render_args;
 
 /* Text of the last error on this thread ("" if none). */

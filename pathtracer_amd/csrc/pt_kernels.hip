@@ -17,6 +17,9 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <cmath>
+#include <vector>
+
 #define PT_NS pt_strict
 #define PT_FAST_MATH 0
 #include "pt_render_kernels.h"
@@ -122,6 +125,11 @@ struct pt_ctx {
 	uint64_t *hostSeedmul; int nHostSeeds;   // what seedmul holds, to skip identical re-uploads
 	unsigned long long *counter;
 	unsigned int *queue;          // pixel queue head of the streaming kernel
+	float4 *hostSpheres;          // cx, cy, cz, radius of the uploaded scene (host copy, for the grid build)
+	// opt-in uniform grid (built on first use after a scene upload)
+	bool gridBuilt;
+	GridTables grid;
+	int *dCellStart, *dItems, *dBig; size_t capCells, capItems, capBig;
 	unsigned char *u8; size_t capU8;
 	hipEvent_t evStart, evStop;
 	hipEvent_t ring[2 * PT_TIMING_SLOTS];   // start/stop pairs of launches made with record_timing
@@ -164,7 +172,9 @@ extern "C" int pt_ctx_destroy(pt_ctx *c) {
 	(void)hipSetDevice(c->device);
 	(void)hipStreamSynchronize(c->stream);
 	(void)hipFree(c->image); (void)hipFree(c->geom); (void)hipFree(c->matA); (void)hipFree(c->matB);
-	(void)hipFree(c->seedmul); (void)hipFree(c->counter); (void)hipFree(c->queue); (void)hipFree(c->u8);
+	(void)hipFree(c->seedmul); (void)hipFree(c->counter); (void)hipFree(c->queue);
+	(void)hipFree(c->dCellStart); (void)hipFree(c->dItems); (void)hipFree(c->dBig);
+	free(c->hostSpheres); (void)hipFree(c->u8);
 	(void)hipEventDestroy(c->evStart); (void)hipEventDestroy(c->evStop);
 	for(int i = 0; i < 2 * PT_TIMING_SLOTS; i++) (void)hipEventDestroy(c->ring[i]);
 	(void)hipStreamDestroy(c->stream);
@@ -197,7 +207,15 @@ extern "C" int pt_scene_upload(pt_ctx *c, const float *spheres, int n) {
 		c->capSpheres = n;
 	}
 	c->nSpheres = n;
+	c->gridBuilt = false;
+	free(c->hostSpheres); c->hostSpheres = NULL;
 	if(n == 0) return PT_OK;
+	c->hostSpheres = (float4 *)malloc(sizeof(float4) * (size_t)n);
+	if(!c->hostSpheres) return fail(PT_E_NOMEM, "pt_scene_upload: host allocation failed%s", NULL);
+	for(int i = 0; i < n; i++) {
+		const float *r = spheres + PT_SPHERE_FLOATS * (size_t)i;
+		c->hostSpheres[i] = make_float4(r[0], r[1], r[2], r[3]);
+	}
 	float4 *h = (float4 *)malloc(sizeof(float4) * 3 * (size_t)n);
 	if(!h) return fail(PT_E_NOMEM, "pt_scene_upload: host allocation failed%s", NULL);
 	float4 *hg = h, *ha = h + n, *hb = h + 2 * (size_t)n;
@@ -222,6 +240,123 @@ extern "C" int pt_scene_upload(pt_ctx *c, const float *spheres, int n) {
 	return PT_OK;
 }
 
+// ---------------------------------------------------------------------------------------
+// Uniform grid build (host).  Spheres whose padded box would cover more than PT_GRID_BIG_CELLS cells of the
+// grid go to the `big` list instead (the walls of the reference's scene are spheres of radius 10^4).
+// ---------------------------------------------------------------------------------------
+#define PT_GRID_BIG_CELLS 512
+#define PT_GRID_MAX_AXIS 256
+
+static int grow_int(int **d, size_t *cap, size_t need) {
+	if(need <= *cap) return PT_OK;
+	if(*d) { (void)hipFree(*d); *d = NULL; *cap = 0; }
+	hipError_t e = hipMalloc((void **)d, sizeof(int) * need);
+	if(e != hipSuccess) { snprintf(g_err, sizeof g_err, "grid hipMalloc failed: %s", hipGetErrorString(e)); return PT_E_NOMEM; }
+	*cap = need;
+	return PT_OK;
+}
+
+static int build_grid(pt_ctx *c) {
+	const int n = c->nSpheres;
+	const float4 *sp = c->hostSpheres;
+	std::vector<char> isBig((size_t)n, 0);
+	GridTables G;
+	memset(&G, 0, sizeof G);
+	std::vector<int> cellStart, items, big;
+	// two rounds: the first sizes the grid over everything and finds the spheres that are too large for it,
+	// the second sizes it over the rest
+	for(int round = 0; round < 3; round++) {
+		double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+		long nSmall = 0;
+		for(int i = 0; i < n; i++) {
+			if(isBig[i]) continue;
+			const double cc[3] = {sp[i].x, sp[i].y, sp[i].z}, r = fabs((double)sp[i].w);
+			if(!(std::isfinite(cc[0]) && std::isfinite(cc[1]) && std::isfinite(cc[2]) && std::isfinite(r))) { isBig[i] = 1; continue; }
+			for(int ax = 0; ax < 3; ax++) { lo[ax] = fmin(lo[ax], cc[ax] - r); hi[ax] = fmax(hi[ax], cc[ax] + r); }
+			nSmall++;
+		}
+		if(nSmall == 0) { G.gx = G.gy = G.gz = 0; break; }
+		double ext[3], vol = 1;
+		for(int ax = 0; ax < 3; ax++) { ext[ax] = fmax(hi[ax] - lo[ax], 1e-3); vol *= ext[ax]; }
+		double cell = cbrt(vol * 2.0 / (double)nSmall);          // about two spheres per cell
+		const double emax = fmax(ext[0], fmax(ext[1], ext[2]));
+		cell = fmax(cell, emax / PT_GRID_MAX_AXIS);
+		const double pad = 0.1 * cell;
+		int g[3];
+		for(int ax = 0; ax < 3; ax++) {
+			lo[ax] -= 2 * pad; hi[ax] += 2 * pad;
+			g[ax] = (int)ceil((hi[ax] - lo[ax]) / cell);
+			if(g[ax] < 1) g[ax] = 1;
+			if(g[ax] > PT_GRID_MAX_AXIS + 8) g[ax] = PT_GRID_MAX_AXIS + 8;
+		}
+		G.gx = g[0]; G.gy = g[1]; G.gz = g[2];
+		G.minx = (float)lo[0]; G.miny = (float)lo[1]; G.minz = (float)lo[2];
+		G.cell = (float)cell; G.invCell = 1.0f / G.cell;
+		G.maxx = G.minx + G.cell * (float)g[0]; G.maxy = G.miny + G.cell * (float)g[1]; G.maxz = G.minz + G.cell * (float)g[2];
+		// cell ranges per sphere, with the same float cell arithmetic the kernel uses and a tenth of a cell of padding
+		auto range = [&](int i, int *a0, int *a1) {
+			const float cc[3] = {sp[i].x, sp[i].y, sp[i].z}, r = fabsf(sp[i].w);
+			const float mn[3] = {G.minx, G.miny, G.minz};
+			const float eps = (float)pad + 1e-3f * r + 1e-5f * fmaxf(fabsf(cc[0]), fmaxf(fabsf(cc[1]), fabsf(cc[2])));
+			long cells = 1;
+			for(int ax = 0; ax < 3; ax++) {
+				int l = (int)floorf((cc[ax] - r - eps - mn[ax]) * G.invCell) , h = (int)floorf((cc[ax] + r + eps - mn[ax]) * G.invCell);
+				l = l < 0 ? 0 : l; h = h >= g[ax] ? g[ax] - 1 : h;
+				if(h < l) h = l;
+				a0[ax] = l; a1[ax] = h;
+				cells *= (h - l + 1);
+			}
+			return cells;
+		};
+		bool changed = false;
+		if(round < 2)
+			for(int i = 0; i < n; i++) {
+				if(isBig[i]) continue;
+				int a0[3], a1[3];
+				if(range(i, a0, a1) > PT_GRID_BIG_CELLS) { isBig[i] = 1; changed = true; }
+			}
+		if(changed) continue;
+		const size_t nc = (size_t)g[0] * g[1] * g[2];
+		cellStart.assign(nc + 1, 0);
+		for(int pass = 0; pass < 2; pass++) {
+			if(pass == 1) {
+				size_t run = 0;
+				for(size_t k = 0; k <= nc; k++) { size_t v = (size_t)cellStart[k]; cellStart[k] = (int)run; run += v; }
+				items.assign(run, 0);
+			}
+			std::vector<int> fill;
+			if(pass == 1) fill.assign(cellStart.begin(), cellStart.end() - 1);
+			for(int i = 0; i < n; i++) {
+				if(isBig[i]) continue;
+				int a0[3], a1[3];
+				range(i, a0, a1);
+				for(int z = a0[2]; z <= a1[2]; z++)
+					for(int y = a0[1]; y <= a1[1]; y++)
+						for(int x = a0[0]; x <= a1[0]; x++) {
+							const size_t cellIdx = ((size_t)z * g[1] + y) * g[0] + x;
+							if(pass == 0) cellStart[cellIdx]++;
+							else items[(size_t)fill[cellIdx]++] = i;
+						}
+			}
+		}
+		break;
+	}
+	for(int i = 0; i < n; i++) if(isBig[i]) big.push_back(i);
+	if(G.gx == 0) { cellStart.assign(2, 0); items.clear(); }
+	G.nBig = (int)big.size();
+	int rc;
+	if((rc = grow_int(&c->dCellStart, &c->capCells, cellStart.size() + 1)) != PT_OK) return rc;
+	if((rc = grow_int(&c->dItems, &c->capItems, items.size() + 1)) != PT_OK) return rc;
+	if((rc = grow_int(&c->dBig, &c->capBig, big.size() + 1)) != PT_OK) return rc;
+	HIP_TRY(hipMemcpy(c->dCellStart, cellStart.data(), sizeof(int) * cellStart.size(), hipMemcpyHostToDevice));
+	if(!items.empty()) HIP_TRY(hipMemcpy(c->dItems, items.data(), sizeof(int) * items.size(), hipMemcpyHostToDevice));
+	if(!big.empty()) HIP_TRY(hipMemcpy(c->dBig, big.data(), sizeof(int) * big.size(), hipMemcpyHostToDevice));
+	G.cellStart = c->dCellStart; G.items = c->dItems; G.big = c->dBig;
+	c->grid = G;
+	c->gridBuilt = true;
+	return PT_OK;
+}
+
 static int local_rows(int H, int rank, int world, int band) {
 	// rows r with (r / band) % world == rank
 	int rows = 0;
@@ -238,6 +373,7 @@ extern "C" int pt_render(pt_ctx *c, const pt_render_args *a) {
 	if(a->width <= 0 || a->height <= 0 || a->max_depth < 0 || a->n_frames < 0 || a->first_frame < 0)
 		return fail(PT_E_INVALID, "pt_render: bad image/sample arguments%s", NULL);
 	if((long long)a->width * a->height > (1ll << 30)) return fail(PT_E_INVALID, "pt_render: image too large%s", NULL);
+	if(a->accel != 0 && a->accel != 1) return fail(PT_E_INVALID, "pt_render: unknown accel%s", NULL);
 	if(a->world < 1 || a->rank < 0 || a->rank >= a->world || a->band_rows < 1)
 		return fail(PT_E_INVALID, "pt_render: bad partition (rank/world/band_rows)%s", NULL);
 	if(a->n_frames > 0 && !a->seeds) return fail(PT_E_INVALID, "pt_render: NULL seeds%s", NULL);
@@ -313,6 +449,17 @@ extern "C" int pt_render(pt_ctx *c, const pt_render_args *a) {
 	if(force && strcmp(force, "v1") == 0) la.kernel = PT_K_V1;
 	if(force && strcmp(force, "stream") == 0 && c->nSpheres > 0) la.kernel = PT_K_STREAM;
 	if(force && strcmp(force, "lds") == 0 && c->nSpheres <= PT_LDS_MAX_SPHERES) la.kernel = PT_K_LDS;
+	// opt-in acceleration structure (no reference counterpart): same closest hit, found through a uniform grid
+	bool accel = a->accel == 1;
+	const char *acc = getenv("PT_ACCEL");
+	if(acc && strcmp(acc, "grid") == 0) accel = true;
+	if(acc && strcmp(acc, "none") == 0) accel = false;
+	memset(&la.grid, 0, sizeof la.grid);
+	if(accel && c->nSpheres > 0 && la.kernel != PT_K_V1) {
+		if(!c->gridBuilt) { int rc = build_grid(c); if(rc != PT_OK) return rc; }
+		la.grid = c->grid;
+		la.kernel = PT_K_GRID;
+	}
 	la.ldsBytes = la.kernel == PT_K_LDS ? 3 * sizeof(float4) * (size_t)c->nSpheres : 0;
 	// streaming kernel: persistent one-wave blocks, at most 32 per CU; surplus pixels come through the queue
 	const long long swaves = (lp + 63) / 64;
@@ -323,7 +470,7 @@ extern "C" int pt_render(pt_ctx *c, const pt_render_args *a) {
 	if(math && strcmp(math, "fast") == 0) fast = true;
 	if(math && strcmp(math, "strict") == 0) fast = false;
 
-	if(la.kernel == PT_K_STREAM) HIP_TRY(hipMemsetAsync(c->queue, 0, 256, st));     // before the start event: not kernel time
+	if(la.kernel == PT_K_STREAM || la.kernel == PT_K_GRID) HIP_TRY(hipMemsetAsync(c->queue, 0, 256, st));     // before the start event: not kernel time
 	if(a->bounce_count) {
 		HIP_TRY(hipMemsetAsync(c->counter, 0, sizeof(unsigned long long), st));
 		if(fast) pt_fast::launch_render(la); else pt_strict::launch_render(la);

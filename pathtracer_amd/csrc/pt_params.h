@@ -33,6 +33,21 @@ struct SceneTables {
 };
 
 
+// Uniform grid over the small spheres of the scene (opt-in acceleration structure, no reference counterpart:
+// src/cl/ray.cl:101-110 is a linear scan).  Cell (x, y, z) lists the spheres whose inflated bounding box
+// overlaps it: items[cellStart[cell] .. cellStart[cell + 1]).  Spheres too large for the grid are in big[]
+// and are tested for every ray.
+struct GridTables {
+	const int *cellStart;
+	const int *items;
+	const int *big;
+	int nBig;
+	int gx, gy, gz;
+	float minx, miny, minz;
+	float maxx, maxy, maxz;
+	float cell, invCell;
+};
+
 // One render launch, as pt_render() hands it to a kernel build.
 struct LaunchArgs {
 	float4 *image;
@@ -47,8 +62,9 @@ struct LaunchArgs {
 	unsigned gridPixels;          // blocks of 256 threads over localPixels << logS
 	unsigned gridStream;          // one-wave blocks of the streaming kernel
 	size_t ldsBytes;
+	GridTables grid;              // PT_K_GRID only
 };
-enum { PT_K_LDS = 0, PT_K_STREAM = 1, PT_K_V1 = 2 };
+enum { PT_K_LDS = 0, PT_K_STREAM = 1, PT_K_V1 = 2, PT_K_GRID = 3 };
 
 namespace pt_strict { void launch_render(const LaunchArgs &la); }
 namespace pt_fast { void launch_render(const LaunchArgs &la); }

@@ -440,6 +440,102 @@ __global__ __launch_bounds__(256) void pt_render_lds_kernel(float4 *__restrict__
 }
 
 // ---------------------------------------------------------------------------------------
+// Closest hit through the uniform grid (opt-in extension; the reference scans linearly).
+// Every sphere that is tested is tested with the reference's own arithmetic (sphere_disc, sqrtf, divide)
+// and the winner is the lexicographic minimum of (rounded t, index) — what the linear scan of
+// src/cl/ray.cl:101-110 returns — so the result is the reference's whenever the reference's winner is
+// among the spheres tested.  It is: the ray is walked cell by cell (3D-DDA) in order of increasing t, a
+// sphere is listed in every cell its bounding box, inflated by a tenth of a cell, overlaps — far more
+// than the rounding error of the walk or of a grazing hit's t — and the walk only stops after finishing a
+// cell whose exit lies beyond the best t found, with a relative margin of 1e-4.  Spheres outside the grid
+// (big[]) are tested first, for every ray.  tests/test_gpu_grid.py checks bit-identity with the linear
+// scan on dense scenes.
+// ---------------------------------------------------------------------------------------
+PT_DEV void grid_test(const float4 *__restrict__ geom, int i, f3 o, f3 d, float a, uint32_t &bk, int &bi) {
+	float bHalf, disc;
+	sphere_disc(geom[i], o, d, a, bHalf, disc);
+	if(!(disc < 0.0f)) {                                               // ray.cl:78
+		const float t = pt_div(-bHalf - sqrt_cr(disc), a);             // ray.cl:80 (sqrt_cr == sqrtf, pt_device.h)
+		const uint32_t key = __float_as_uint(t) - 1u;                  // t > 0 (ray.cl:82) <=> key < bits(+inf)
+		if(key < bk || (key == bk && i < bi)) { bk = key; bi = i; }
+	}
+}
+
+PT_DEV Hit closest_hit_grid(const GridTables &G, const float4 *__restrict__ geom, f3 o, f3 d, float a) {
+	uint32_t bk = 0x7f800000u;
+	int bi = 0x7fffffff;
+	for(int k = 0; k < G.nBig; k++) grid_test(geom, G.big[k], o, d, a, bk, bi);
+	// slab test against the grid box, in the ray's own parameter (d is not normalised)
+	float t0 = 0.0f, t1 = __builtin_inff();
+	bool inside = true;
+	const float oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z};
+	const float lo[3] = {G.minx, G.miny, G.minz}, hi[3] = {G.maxx, G.maxy, G.maxz};
+	float inv[3];
+#pragma unroll
+	for(int ax = 0; ax < 3; ax++) {
+		if(dd[ax] != 0.0f) {
+			inv[ax] = 1.0f / dd[ax];
+			const float ta = (lo[ax] - oo[ax]) * inv[ax], tb = (hi[ax] - oo[ax]) * inv[ax];
+			t0 = fmaxf(t0, fminf(ta, tb));
+			t1 = fminf(t1, fmaxf(ta, tb));
+		} else {
+			inv[ax] = __builtin_inff();
+			if(!(oo[ax] >= lo[ax] && oo[ax] <= hi[ax])) inside = false;
+		}
+	}
+	// the box is already padded by a cell-tenth beyond every listed sphere; keep rays that graze it
+	if(inside && t0 <= t1 * (1.0f + 1e-4f) + 1e-30f && (G.gx | G.gy | G.gz) != 0) {
+		const float ts = t0 * (1.0f - 1e-5f);
+		const int g[3] = {G.gx, G.gy, G.gz};
+		int ic[3], step[3];
+		float tMax[3], tDelta[3];
+#pragma unroll
+		for(int ax = 0; ax < 3; ax++) {
+			const float pos = oo[ax] + dd[ax] * ts;
+			int c = (int)floorf((pos - lo[ax]) * G.invCell);
+			c = c < 0 ? 0 : (c >= g[ax] ? g[ax] - 1 : c);
+			ic[ax] = c;
+			if(dd[ax] > 0.0f) {
+				step[ax] = 1;
+				tMax[ax] = (lo[ax] + (float)(c + 1) * G.cell - oo[ax]) * inv[ax];
+				tDelta[ax] = G.cell * inv[ax];
+			} else if(dd[ax] < 0.0f) {
+				step[ax] = -1;
+				tMax[ax] = (lo[ax] + (float)c * G.cell - oo[ax]) * inv[ax];
+				tDelta[ax] = -G.cell * inv[ax];
+			} else {
+				step[ax] = 0;
+				tMax[ax] = __builtin_inff();
+				tDelta[ax] = __builtin_inff();
+			}
+		}
+		// a walk visits at most gx + gy + gz cells
+		for(int guard = g[0] + g[1] + g[2] + 3; guard > 0; guard--) {
+			const int cellIdx = (ic[2] * g[1] + ic[1]) * g[0] + ic[0];
+			const int cb = G.cellStart[cellIdx], ce = G.cellStart[cellIdx + 1];
+			for(int k = cb; k < ce; k++) grid_test(geom, G.items[k], o, d, a, bk, bi);
+			const float tExit = fminf(tMax[0], fminf(tMax[1], tMax[2]));
+			if(bk < 0x7f800000u && __uint_as_float(bk + 1u) < tExit * (1.0f - 1e-4f)) break;
+			if(tMax[0] <= tMax[1] && tMax[0] <= tMax[2]) {
+				ic[0] += step[0]; tMax[0] += tDelta[0];
+				if(ic[0] < 0 || ic[0] >= g[0]) break;
+			} else if(tMax[1] <= tMax[2]) {
+				ic[1] += step[1]; tMax[1] += tDelta[1];
+				if(ic[1] < 0 || ic[1] >= g[1]) break;
+			} else {
+				ic[2] += step[2]; tMax[2] += tDelta[2];
+				if(ic[2] < 0 || ic[2] >= g[2]) break;
+			}
+		}
+	}
+	Hit h;
+	h.hit = bk < 0x7f800000u;
+	h.t = __uint_as_float(bk + 1u);
+	h.idx = h.hit ? bi : 0;
+	return h;
+}
+
+// ---------------------------------------------------------------------------------------
 // Streaming kernel (tables that do not fit in LDS: BASELINE config 3, 10^4-10^5 spheres).
 // One wave per block, persistent: waves pull pixels from a device-wide queue until it is empty.
 //  * A lane owns ONE pixel at a time and runs its samples in order k = 0, 1, ... (the running mean
@@ -457,11 +553,11 @@ __global__ __launch_bounds__(256) void pt_render_lds_kernel(float4 *__restrict__
 #define PT_COOP_MAX_LANES 16   // at or below this many tracing lanes the wave scans ray by ray, 64 spheres per step
 #define PT_PAD_SPHERE make_float4(0.0f, 0.0f, 0.0f, -__builtin_inff())   // r^2 = -inf: disc = -inf, never a candidate
 
-template <bool COUNT>
+template <bool COUNT, bool GRID>
 __global__ __launch_bounds__(64) void pt_render_stream_kernel(float4 *__restrict__ image, const KParams p, const SceneTables sc,
                                                                const uint64_t *__restrict__ seedmul,
                                                                unsigned long long *__restrict__ bounceCounter,
-                                                               unsigned int *__restrict__ queue) {
+                                                               unsigned int *__restrict__ queue, const GridTables grid) {
 	__shared__ float4 sChunk[2][PT_CHUNK];
 	const int lane = (int)threadIdx.x;
 	const int nchunks = (p.n + PT_CHUNK - 1) / PT_CHUNK;
@@ -474,7 +570,7 @@ __global__ __launch_bounds__(64) void pt_render_stream_kernel(float4 *__restrict
 	pt.o = pt.d = pt.mask = mk3(0.0f, 0.0f, 0.0f);
 	pt.rng = 0;
 	f3 origin = mk3(0.0f, 0.0f, 0.0f), acc = mk3(0.0f, 0.0f, 0.0f);
-	if(nchunks == 1) {
+	if(!GRID && nchunks == 1) {
 		sChunk[0][lane] = lane < p.n ? sc.geom[lane] : PT_PAD_SPHERE;
 		sChunk[0][lane + 64] = lane + 64 < p.n ? sc.geom[lane + 64] : PT_PAD_SPHERE;
 		__syncthreads();
@@ -522,7 +618,11 @@ __global__ __launch_bounds__(64) void pt_render_stream_kernel(float4 *__restrict
 		h.hit = false; h.t = 0.0f; h.idx = 0;
 		const unsigned long long tmask = __builtin_amdgcn_ballot_w64(tracing);
 		unsigned long long coop = tmask;      // lanes whose ray the whole wave scans together
-		if(__popcll(tmask) > PT_COOP_MAX_LANES) {
+		if(GRID) {
+			// opt-in: every lane walks the grid for its own ray
+			if(tracing) h = closest_hit_grid(grid, sc.geom, pt.o, pt.d, a);
+			coop = 0;
+		} else if(__popcll(tmask) > PT_COOP_MAX_LANES) {
 			// ray-parallel: every lane scans the whole table for its own ray
 			uint32_t best = KEY_NONE, prev = KEY_NONE;
 			float tiny = __builtin_inff();
@@ -602,8 +702,11 @@ void launch_render(const LaunchArgs &la) {
 		if(la.count) hipLaunchKernelGGL(pt_render_kernel<true>, grid, block, 0, la.stream, la.image, la.p, la.sc, la.seedmul, la.bounceCounter);
 		else hipLaunchKernelGGL(pt_render_kernel<false>, grid, block, 0, la.stream, la.image, la.p, la.sc, la.seedmul, la.bounceCounter);
 	} else {
-		if(la.count) hipLaunchKernelGGL(pt_render_stream_kernel<true>, sgrid, dim3(64), 0, la.stream, la.image, la.p, la.sc, la.seedmul, la.bounceCounter, la.queue);
-		else hipLaunchKernelGGL(pt_render_stream_kernel<false>, sgrid, dim3(64), 0, la.stream, la.image, la.p, la.sc, la.seedmul, la.bounceCounter, la.queue);
+		const bool g = la.kernel == PT_K_GRID;
+		if(la.count && g) hipLaunchKernelGGL((pt_render_stream_kernel<true, true>), sgrid, dim3(64), 0, la.stream, la.image, la.p, la.sc, la.seedmul, la.bounceCounter, la.queue, la.grid);
+		else if(la.count) hipLaunchKernelGGL((pt_render_stream_kernel<true, false>), sgrid, dim3(64), 0, la.stream, la.image, la.p, la.sc, la.seedmul, la.bounceCounter, la.queue, la.grid);
+		else if(g) hipLaunchKernelGGL((pt_render_stream_kernel<false, true>), sgrid, dim3(64), 0, la.stream, la.image, la.p, la.sc, la.seedmul, la.bounceCounter, la.queue, la.grid);
+		else hipLaunchKernelGGL((pt_render_stream_kernel<false, false>), sgrid, dim3(64), 0, la.stream, la.image, la.p, la.sc, la.seedmul, la.bounceCounter, la.queue, la.grid);
 	}
 }
 

@@ -34,6 +34,7 @@ class RenderArgs(C.Structure):
         ("kernel_ms", C.POINTER(C.c_float)),
         ("record_timing", C.c_int),
         ("fast_math", C.c_int),
+        ("accel", C.c_int),
     ]
 
 
@@ -113,7 +114,7 @@ class Context:
         _check(self.lib.pt_scene_upload(self.h, sp.ctypes.data_as(C.POINTER(C.c_float)), sp.shape[0]), "pt_scene_upload")
 
     def render(self, scene, width, height, max_depth, seeds, first_frame=0, rank=0, world=1, band_rows=16,
-               d_image=None, stream=None, count_bounces=False, async_=False, time_kernel=False, record_timing=False, fast_math=False):
+               d_image=None, stream=None, count_bounces=False, async_=False, time_kernel=False, record_timing=False, fast_math=False, accel=0):
         """scene: dict with 'bg' and 'cam' (pathtracer_amd.scenes layout); the spheres must have
         been uploaded with scene_upload().  Returns the bounce count (count_bounces) or the
         HIP-event kernel time in ms (time_kernel) if asked, else None."""
@@ -138,6 +139,7 @@ class Context:
         a.kernel_ms = C.pointer(ms) if time_kernel else None
         a.record_timing = 1 if record_timing else 0
         a.fast_math = 1 if fast_math else 0
+        a.accel = int(accel)
         _check(self.lib.pt_render(self.h, C.byref(a)), "pt_render")
         if time_kernel:
             return float(ms.value)
