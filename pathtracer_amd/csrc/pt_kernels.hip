@@ -4,13 +4,14 @@
 // src/cl/rng.cl) and the device side of its host loop (src/c/renderer.c:153-262).
 // Not a translation: one launch renders ALL samples of a pixel with the accumulator in
 // registers (the reference re-launches per sample and read-modify-writes 32 B per sample
-// per pixel), the scene is structure-of-arrays (geometry table read through wave-uniform
-// scalar loads, material table gathered only for the winning sphere), the RNG is 32-bit
-// with Mersenne folding instead of 64-bit remainders, and per-launch uniform
-// trigonometry is folded on the host.
+// per pixel), the scene is structure-of-arrays (geometry table staged in LDS and read as
+// wave-uniform broadcasts, material table gathered only for the winning sphere), the RNG is
+// 32-bit with Mersenne folding instead of 64-bit remainders, and per-launch uniform
+// trigonometry is folded on the host.  The render kernels themselves are in
+// pt_render_kernels.h (built here as pt_strict, in pt_kernels_fast.hip as pt_fast).
 //
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fno-fast-math
-//        -fhip-fp32-correctly-rounded-divide-sqrt  (see __graft_entry__.build()).
+//        -fhip-fp32-correctly-rounded-divide-sqrt -fno-slp-vectorize  (see __graft_entry__.build()).
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdio.h>
@@ -444,9 +445,8 @@ extern "C" int pt_render(pt_ctx *c, const pt_render_args *a) {
 	// table would still fit in LDS, because its scan skips the spheres no lane can hit and its lanes never idle
 	// (1080p, 500 random spheres: 27.7 ms lock-step, 8.2 ms streaming; 40 spheres in a closed box: 114 vs 108 ms;
 	// the 9-sphere box: 60 vs 107 ms).
-	const char *force = getenv("PT_KERNEL");      // debugging aid: "v1" (first, scalar-load kernel), "stream", "lds"
+	const char *force = getenv("PT_KERNEL");      // debugging aid: "stream" or "lds" overrides the choice
 	la.kernel = c->nSpheres <= PT_LOCKSTEP_MAX_SPHERES ? PT_K_LDS : PT_K_STREAM;
-	if(force && strcmp(force, "v1") == 0) la.kernel = PT_K_V1;
 	if(force && strcmp(force, "stream") == 0 && c->nSpheres > 0) la.kernel = PT_K_STREAM;
 	if(force && strcmp(force, "lds") == 0 && c->nSpheres <= PT_LDS_MAX_SPHERES) la.kernel = PT_K_LDS;
 	// opt-in acceleration structure (no reference counterpart): same closest hit, found through a uniform grid
@@ -455,7 +455,7 @@ extern "C" int pt_render(pt_ctx *c, const pt_render_args *a) {
 	if(acc && strcmp(acc, "grid") == 0) accel = true;
 	if(acc && strcmp(acc, "none") == 0) accel = false;
 	memset(&la.grid, 0, sizeof la.grid);
-	if(accel && c->nSpheres > 0 && la.kernel != PT_K_V1) {
+	if(accel && c->nSpheres > 0) {
 		if(!c->gridBuilt) { int rc = build_grid(c); if(rc != PT_OK) return rc; }
 		la.grid = c->grid;
 		la.kernel = PT_K_GRID;

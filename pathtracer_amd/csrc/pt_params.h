@@ -64,7 +64,7 @@ struct LaunchArgs {
 	size_t ldsBytes;
 	GridTables grid;              // PT_K_GRID only
 };
-enum { PT_K_LDS = 0, PT_K_STREAM = 1, PT_K_V1 = 2, PT_K_GRID = 3 };
+enum { PT_K_LDS = 0, PT_K_STREAM = 1, PT_K_GRID = 3 };
 
 namespace pt_strict { void launch_render(const LaunchArgs &la); }
 namespace pt_fast { void launch_render(const LaunchArgs &la); }

@@ -34,98 +34,6 @@ PT_DEV f3 camera_origin(const KParams &p, int id) {
 }
 
 // ---------------------------------------------------------------------------------------
-// Kernel v1: one thread per pixel, all samples in-kernel, lock-step sample loop.
-// ---------------------------------------------------------------------------------------
-template <bool COUNT>
-__global__ __launch_bounds__(256) void pt_render_kernel(float4 *__restrict__ image, const KParams p, const SceneTables sc,
-                                                         const uint64_t *__restrict__ seedmul,
-                                                         unsigned long long *__restrict__ bounceCounter) {
-	const int id = pixel_id(p, (int)(blockIdx.x * blockDim.x + threadIdx.x));
-	unsigned int myBounces = 0;
-	if(id >= 0) {
-		const f3 pos = mk3(p.px, p.py, p.pz);
-		const f3 origin = camera_origin(p, id);
-		f3 acc = mk3(0.0f, 0.0f, 0.0f);
-		if(p.firstFrame > 0) {
-			float4 v = image[id];
-			acc = mk3(v.x, v.y, v.z);
-		}
-		for(int k = 0; k < p.nFrames; k++) {
-			uint32_t rng = init_rng_2((uint32_t)id, seedmul[k]);                       // main.cl:6
-			f3 target = add3(pos, scl3(random_unit_vector(rng), p.aperture));            // main.cl:19
-			f3 d = norm3(sub3(target, origin));                                          // main.cl:21
-			f3 o = pos;                                                                  // main.cl:23
-			f3 color = mk3(0.0f, 0.0f, 0.0f), mask = mk3(1.0f, 1.0f, 1.0f);              // ray.cl:92-93
-			for(int j = 0; j < p.maxDepth; j++) {                                        // ray.cl:96
-				if(COUNT) myBounces++;
-				const float ln = len3(d);
-				const float a = ln * ln;                                                 // ray.cl:73 pow(length(d),2)
-				bool hit = false;
-				float distance = 0.0f;
-				int idx = 0;
-				for(int i = 0; i < p.n; i++) {                                           // ray.cl:101-110
-					const float4 g = sc.geom[i];
-					const f3 oc = sub3(o, mk3(g.x, g.y, g.z));
-					const float bHalf = dot3(oc, d);
-					const float c = oc.x * oc.x + oc.y * oc.y + oc.z * oc.z - g.w;
-					const float disc = bHalf * bHalf - a * c;
-					if(!(disc < 0.0f)) {
-						const float t = (-bHalf - sqrtf(disc)) / a;
-						if(t > 0.0f && (!hit || t < distance)) { hit = true; distance = t; idx = i; }
-					}
-				}
-				if(!hit) { color = mul3(mask, mk3(p.bgx, p.bgy, p.bgz)); break; }      // ray.cl:112-115
-				const float4 g = sc.geom[idx];
-				const float4 mA = sc.matA[idx];
-				const float4 mB = sc.matB[idx];
-				const int type = __float_as_int(mA.w);
-				const f3 mcol = mk3(mA.x, mA.y, mA.z);
-				const f3 hitPos = add3(o, scl3(d, distance));                            // ray.cl:117
-				f3 normal = norm3(sub3(hitPos, mk3(g.x, g.y, g.z)));                     // ray.cl:118
-				const f3 offPos = sub3(hitPos, scl3(normal, 0.0001f));                   // ray.cl:119
-				bool front = true;
-				if(dot3(d, normal) > 0.0f) { front = false; normal = scl3(normal, -1.0f); }   // ray.cl:122-128
-				if(type == 0) {                                                          // ray.cl:130-134
-					if(front) { color = mul3(mask, mcol); break; }
-				} else if(type == 1) {                                                   // ray.cl:136-141
-					if(front) {
-						d = add3(normal, random_unit_vector(rng));
-						o = offPos;
-						mask = mul3(mask, mcol);
-					}
-				} else if(type == 2) {                                                   // ray.cl:143-148
-					if(front) {
-						d = add3(reflection_dir(d, normal), scl3(random_unit_vector(rng), mB.y));
-						o = offPos;
-						mask = add3(scl3(mask, 1.0f - mB.x), scl3(mul3(mask, mcol), mB.x));
-					}
-				} else if(type == 3) {                                                   // ray.cl:150-171
-					const float rel = front ? mB.z : pt_div(1.0f, mB.z);
-					const float cosTheta = fminf(dot3(scl3(d, -1.0f), normal), 1.0f);
-					const float sinTheta = sqrtf(1.0f - cosTheta * cosTheta);
-					bool reflect = rel * sinTheta > 1.0f;
-					if(!reflect) reflect = reflectance(cosTheta, rel) > rand_float(rng);    // short-circuit draw, ray.cl:163
-					const f3 base = reflect ? reflection_dir(d, normal) : refraction_dir(d, normal, rel);
-					d = add3(base, scl3(random_unit_vector(rng), mB.y));
-					o = offPos;
-					mask = add3(scl3(mask, 1.0f - mB.x), scl3(mul3(mask, mcol), mB.x));
-				}
-			}
-			color = scl3(scl3(color, p.exposure), p.aperture);                           // main.cl:27
-			const float f = (float)(p.firstFrame + k), f1 = (float)(p.firstFrame + k + 1);
-			acc = mk3((acc.x * f + color.x) / f1, (acc.y * f + color.y) / f1, (acc.z * f + color.z) / f1);   // main.cl:29
-		}
-		image[id] = make_float4(acc.x, acc.y, acc.z, COUNT ? (float)myBounces : 0.0f);
-	}
-	if(COUNT) {
-		// wave-level sum, one atomic per wave
-		unsigned int v = myBounces;
-		for(int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-		if((threadIdx.x & 63) == 0 && v) atomicAdd(bounceCounter, (unsigned long long)v);
-	}
-}
-
-// ---------------------------------------------------------------------------------------
 // Per-path state and the pieces every kernel variant shares
 // ---------------------------------------------------------------------------------------
 struct Path {
@@ -365,7 +273,7 @@ PT_DEV Hit closest_hit(const Tab geom, int n, f3 o, f3 d, float a) {
 }
 
 // ---------------------------------------------------------------------------------------
-// Kernel v2 (scenes whose tables fit in LDS): one thread per pixel, all samples in-kernel,
+// Lock-step kernel (small tables, staged whole in LDS): one thread per pixel, all samples in-kernel,
 // lock-step sample loop, geometry and material tables staged in LDS and read back as
 // wave-uniform (geometry) or per-lane (material of the winning sphere) ds_reads, so the
 // arithmetic runs on VGPR operands at full VALU rate.
@@ -698,9 +606,6 @@ void launch_render(const LaunchArgs &la) {
 	if(la.kernel == PT_K_LDS) {
 		if(la.count) hipLaunchKernelGGL(pt_render_lds_kernel<true>, grid, block, la.ldsBytes, la.stream, la.image, la.p, la.sc, la.seedmul, la.bounceCounter);
 		else hipLaunchKernelGGL(pt_render_lds_kernel<false>, grid, block, la.ldsBytes, la.stream, la.image, la.p, la.sc, la.seedmul, la.bounceCounter);
-	} else if(la.kernel == PT_K_V1) {
-		if(la.count) hipLaunchKernelGGL(pt_render_kernel<true>, grid, block, 0, la.stream, la.image, la.p, la.sc, la.seedmul, la.bounceCounter);
-		else hipLaunchKernelGGL(pt_render_kernel<false>, grid, block, 0, la.stream, la.image, la.p, la.sc, la.seedmul, la.bounceCounter);
 	} else {
 		const bool g = la.kernel == PT_K_GRID;
 		if(la.count && g) hipLaunchKernelGGL((pt_render_stream_kernel<true, true>), sgrid, dim3(64), 0, la.stream, la.image, la.p, la.sc, la.seedmul, la.bounceCounter, la.queue, la.grid);
