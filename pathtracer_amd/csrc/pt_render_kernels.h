@@ -72,29 +72,31 @@ PT_DEV bool shade_hit(Path &pt, float t, const float4 g, const float4 mA, const 
 	if(dot3(d, normal) > 0.0f) { front = false; normal = scl3(normal, -1.0f); }          // ray.cl:122-128
 	if(type == 0) {                                                                      // ray.cl:130-134
 		if(front) { color = mul3(pt.mask, mcol); return true; }
-	} else if(type == 1) {                                                               // ray.cl:136-141
-		if(front) {
-			pt.d = add3(normal, random_unit_vector(pt.rng));
-			pt.o = offPos;
-			pt.mask = mul3(pt.mask, mcol);
-		}
-	} else if(type == 2) {                                                               // ray.cl:143-148
-		if(front) {
-			pt.d = add3(reflection_dir(d, normal), scl3(random_unit_vector(pt.rng), mB.y));
-			pt.o = offPos;
-			pt.mask = add3(scl3(pt.mask, 1.0f - mB.x), scl3(mul3(pt.mask, mcol), mB.x));
-		}
-	} else if(type == 3) {                                                               // ray.cl:150-171
-		const float rel = front ? mB.z : pt_div(1.0f, mB.z);
-		const float cosTheta = fminf(dot3(scl3(d, -1.0f), normal), 1.0f);
-		const float sinTheta = sqrt_cr(1.0f - cosTheta * cosTheta);
-		bool reflect = rel * sinTheta > 1.0f;
-		if(!reflect) reflect = reflectance(cosTheta, rel) > rand_float(pt.rng);          // short-circuit draw, ray.cl:163
-		const f3 base = reflect ? reflection_dir(d, normal) : refraction_dir(d, normal, rel);
-		pt.d = add3(base, scl3(random_unit_vector(pt.rng), mB.y));
-		pt.o = offPos;
-		pt.mask = add3(scl3(pt.mask, 1.0f - mB.x), scl3(mul3(pt.mask, mcol), mB.x));
+		return false;                                                                    // back face of a light: the ray is left as it is
 	}
+	if(!front && type != 3) return false;                                                // ray.cl:137,144: only the dielectric scatters from a back face
+	// The three scattering materials all end in `direction = base + random_unit_vector * scale` with the SAME two
+	// RNG draws; only `base`, `scale` and the mask rule differ.  One shared copy of the draw instead of one per
+	// branch: a wave whose lanes hit different materials runs it once (x * 1.0f is x, bit for bit, so the
+	// lambertian `normal + random_unit_vector` of ray.cl:138 is unchanged).
+	f3 base = normal, mask = mul3(pt.mask, mcol);                                        // ray.cl:138,140
+	float scale = 1.0f;
+	if(type != 1) {
+		scale = mB.y;                                                                    // fuzzyness, ray.cl:145,165,168
+		mask = add3(scl3(pt.mask, 1.0f - mB.x), scl3(mask, mB.x));                       // ray.cl:147,170
+		if(type == 2) base = reflection_dir(d, normal);                                  // ray.cl:145
+		else {                                                                           // ray.cl:150-171
+			const float rel = front ? mB.z : pt_div(1.0f, mB.z);
+			const float cosTheta = fminf(dot3(scl3(d, -1.0f), normal), 1.0f);
+			const float sinTheta = sqrt_cr(1.0f - cosTheta * cosTheta);
+			bool reflect = rel * sinTheta > 1.0f;
+			if(!reflect) reflect = reflectance(cosTheta, rel) > rand_float(pt.rng);      // short-circuit draw, ray.cl:163
+			base = reflect ? reflection_dir(d, normal) : refraction_dir(d, normal, rel);
+		}
+	}
+	pt.d = add3(base, scl3(random_unit_vector(pt.rng), scale));
+	pt.o = offPos;
+	pt.mask = mask;
 	return false;
 }
 
