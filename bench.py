@@ -11,8 +11,9 @@ N = 1 : python bench.py [--steps K --warmup W]
 N > 1 : python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N
         one process per GPU; the SAME image is cut into 8-row bands dealt round-robin to the ranks
         (work-item ids stay global, so every pixel is bit-identical to the 1-GPU image), each rank
-        renders its bands into a zeroed full-frame buffer and one RCCL reduce(sum) over xGMI
-        combines them on rank 0 — inside the timed step.  Fixed total work: "scaling": "strong".
+        renders its bands into a zeroed full-frame buffer and one RCCL reduce(sum) over xGMI per step
+        combines them on rank 0 — inside the timed region, overlapped with the next step's render
+        (two frame buffers).  Fixed total work: "scaling": "strong".
 
 Prints ONE JSON line on rank 0.
 """
@@ -131,14 +132,26 @@ def main():
         raise SystemExit("bench.py: at most 256 timed steps (size of the C ABI's kernel-timing ring)")
     barrier()
     t0 = time.perf_counter()
+    # N > 1: two frame buffers, so that the RCCL reduce of step k overlaps the render of step k+1 (the reduce is
+    # asynchronous; a buffer is zeroed again only after the reduce that read it has been waited for)
+    frames = [frame, torch.zeros_like(frame)] if multi else [frame]
+    pending = [None, None]
     for k in range(args.steps):
+        buf = frames[k % len(frames)]
         if multi:
-            frame.zero_()
+            if pending[k % 2] is not None:
+                pending[k % 2].wait()
+            buf.zero_()
         # record_timing: the C ABI brackets the kernel with HIP events on the launch stream, no host sync
         ctx.render(scene, WIDTH, HEIGHT, DEPTH, seeds, rank=rank, world=world, band_rows=BAND_ROWS,
-                   d_image=frame.data_ptr(), stream=stream, async_=True, record_timing=True)
+                   d_image=buf.data_ptr(), stream=stream, async_=True, record_timing=True)
         if multi:
-            dist.reduce(frame, dst=0, op=dist.ReduceOp.SUM)
+            pending[k % 2] = dist.reduce(buf, dst=0, op=dist.ReduceOp.SUM, async_op=True)
+    for w in pending:
+        if w is not None:
+            w.wait()
+    if multi:
+        frame = frames[(args.steps - 1) % 2]       # the last step's reduced image, checked below
     barrier()
     dt = time.perf_counter() - t0
 
