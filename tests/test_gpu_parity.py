@@ -294,3 +294,21 @@ def test_config5_lattice_full_size_rows(ctx, oracle):
         want = oracle.render(sc, W, H, 32, s, id_begin=r * W, id_end=(r + 1) * W)
         assert np.array_equal(bits(img[r, :, :3]), bits(want[r, :, :3])), "row %d" % r
     assert 20.0 < bc / (W * H * 2) < 32.0
+
+
+@pytest.mark.parametrize("kernel", ["lds", "stream"])
+@pytest.mark.parametrize("name", sorted(n for n in CASES if not n.startswith(("dense3000", "dense513", "empty"))))
+def test_both_kernels_on_every_small_fixture(ctx, kernel, name):
+    """The kernel choice is a matter of speed only: the lock-step kernel (default up to 16 spheres) and the persistent
+    streaming kernel (default beyond) must both reproduce the strict reference fixture on every scene either can hold
+    (depth 0 and 1, the stuck RNG of pixel 0, duplicates and ties included)."""
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    W, H, depth, spp = (int(x) for x in g["size"])
+    sc = {"spheres": g["spheres"], "bg": g["bg"], "cam": g["cam"]}
+    try:
+        os.environ["PT_KERNEL"] = kernel
+        img, bc = hip.render_scene(ctx, sc, W, H, depth, g["seeds"], count_bounces=True)
+    finally:
+        os.environ.pop("PT_KERNEL", None)
+    assert np.array_equal(bits(img[..., :3]), bits(g["strict"])), mismatch_report(img[..., :3], g["strict"])
+    assert int(img[..., 3].astype(np.float64).sum()) == bc
