@@ -74,6 +74,68 @@ KERNEL(k_mul_sgpr, F32DECL, "v_mul_f32 %0, s20, %0\n v_mul_f32 %1, s21, %1\n v_m
 KERNEL(k_fma_sgpr, F32DECL, "v_fma_f32 %0, s20, %0, %4\n v_fma_f32 %1, s21, %1, %5\n v_fma_f32 %2, s22, %2, %4\n v_fma_f32 %3, s23, %3, %5\n")
 KERNEL(k_sub_sgpr, F32DECL, "v_subrev_f32 %0, s20, %0\n v_subrev_f32 %1, s21, %1\n v_subrev_f32 %2, s22, %2\n v_subrev_f32 %3, s23, %3\n")
 
+KERNEL(k_ashr_i32, F32DECL, "v_ashrrev_i32 %0, 31, %0\n v_ashrrev_i32 %1, 31, %1\n v_ashrrev_i32 %2, 31, %2\n v_ashrrev_i32 %3, 31, %3\n ")
+KERNEL(k_lshr_b32, F32DECL, "v_lshrrev_b32 %0, 31, %0\n v_lshrrev_b32 %1, 31, %1\n v_lshrrev_b32 %2, 31, %2\n v_lshrrev_b32 %3, 31, %3\n ")
+KERNEL(k_lshl_b32, F32DECL, "v_lshlrev_b32 %0, 1, %0\n v_lshlrev_b32 %1, 1, %1\n v_lshlrev_b32 %2, 1, %2\n v_lshlrev_b32 %3, 1, %3\n ")
+KERNEL(k_sub_u32, F32DECL, "v_sub_u32 %0, %0, %4\n v_sub_u32 %1, %1, %5\n v_sub_u32 %2, %2, %4\n v_sub_u32 %3, %3, %5\n ")
+KERNEL(k_xor_b32, F32DECL, "v_xor_b32 %0, %0, %4\n v_xor_b32 %1, %1, %5\n v_xor_b32 %2, %2, %4\n v_xor_b32 %3, %3, %5\n ")
+KERNEL(k_or_b32, F32DECL, "v_or_b32 %0, %0, %4\n v_or_b32 %1, %1, %5\n v_or_b32 %2, %2, %4\n v_or_b32 %3, %3, %5\n ")
+KERNEL(k_bfe_u32, F32DECL, "v_bfe_u32 %0, %0, 3, 5\n v_bfe_u32 %1, %1, 3, 5\n v_bfe_u32 %2, %2, 3, 5\n v_bfe_u32 %3, %3, 3, 5\n ")
+KERNEL(k_add3_u32, F32DECL, "v_add3_u32 %0, %0, %4, %4\n v_add3_u32 %1, %1, %5, %5\n v_add3_u32 %2, %2, %4, %4\n v_add3_u32 %3, %3, %5, %5\n ")
+KERNEL(k_and_or_b32, F32DECL, "v_and_or_b32 %0, %0, %4, %4\n v_and_or_b32 %1, %1, %5, %5\n v_and_or_b32 %2, %2, %4, %4\n v_and_or_b32 %3, %3, %5, %5\n ")
+KERNEL(k_fmac_f32, F32DECL, "v_fmac_f32 %0, %4, %4\n v_fmac_f32 %1, %5, %5\n v_fmac_f32 %2, %4, %4\n v_fmac_f32 %3, %5, %5\n ")
+KERNEL(k_add_f32_neg, F32DECL, "v_add_f32 %0, -%0, %4\n v_add_f32 %1, -%1, %5\n v_add_f32 %2, -%2, %4\n v_add_f32 %3, -%3, %5\n ")
+KERNEL(k_sub_f32, F32DECL, "v_sub_f32 %0, %0, %4\n v_sub_f32 %1, %1, %5\n v_sub_f32 %2, %2, %4\n v_sub_f32 %3, %3, %5\n ")
+KERNEL(k_add_f32_abs, F32DECL, "v_add_f32 %0, |%0|, %4\n v_add_f32 %1, |%1|, %5\n v_add_f32 %2, |%2|, %4\n v_add_f32 %3, |%3|, %5\n ")
+KERNEL(k_addc_co, F32DECL, "v_addc_co_u32 %0, vcc, 0, %0, vcc\n v_addc_co_u32 %1, vcc, 0, %1, vcc\n v_addc_co_u32 %2, vcc, 0, %2, vcc\n v_addc_co_u32 %3, vcc, 0, %3, vcc\n ")
+KERNEL(k_subb_co, F32DECL, "v_subb_co_u32 %0, vcc, %0, %4, vcc\n v_subb_co_u32 %1, vcc, %1, %5, vcc\n v_subb_co_u32 %2, vcc, %2, %4, vcc\n v_subb_co_u32 %3, vcc, %3, %5, vcc\n ")
+KERNEL(k_add_co, F32DECL, "v_add_co_u32 %0, vcc, %0, %4\n v_add_co_u32 %1, vcc, %1, %5\n v_add_co_u32 %2, vcc, %2, %4\n v_add_co_u32 %3, vcc, %3, %5\n ")
+KERNEL(k_max_u32, F32DECL, "v_max_u32 %0, %0, %4\n v_max_u32 %1, %1, %5\n v_max_u32 %2, %2, %4\n v_max_u32 %3, %3, %5\n ")
+KERNEL(k_med3_u32, F32DECL, "v_med3_u32 %0, %0, %4, %4\n v_med3_u32 %1, %1, %5, %5\n v_med3_u32 %2, %2, %4, %4\n v_med3_u32 %3, %3, %5, %5\n ")
+KERNEL(k_min_i32, F32DECL, "v_min_i32 %0, %0, %4\n v_min_i32 %1, %1, %5\n v_min_i32 %2, %2, %4\n v_min_i32 %3, %3, %5\n ")
+KERNEL(k_bfi_b32, F32DECL, "v_bfi_b32 %0, %0, %4, %4\n v_bfi_b32 %1, %1, %5, %5\n v_bfi_b32 %2, %2, %4, %4\n v_bfi_b32 %3, %3, %5, %5\n ")
+KERNEL(k_perm_b32, F32DECL, "v_perm_b32 %0, %0, %4, %4\n v_perm_b32 %1, %1, %5, %5\n v_perm_b32 %2, %2, %4, %4\n v_perm_b32 %3, %3, %5, %5\n ")
+KERNEL(k_mul_u32_u24, F32DECL, "v_mul_u32_u24 %0, %0, %4\n v_mul_u32_u24 %1, %1, %5\n v_mul_u32_u24 %2, %2, %4\n v_mul_u32_u24 %3, %3, %5\n ")
+KERNEL(k_mad_u32_u24, F32DECL, "v_mad_u32_u24 %0, %0, %4, %4\n v_mad_u32_u24 %1, %1, %5, %5\n v_mad_u32_u24 %2, %2, %4, %4\n v_mad_u32_u24 %3, %3, %5, %5\n ")
+KERNEL(k_xad_u32, F32DECL, "v_xad_u32 %0, %0, %4, %4\n v_xad_u32 %1, %1, %5, %5\n v_xad_u32 %2, %2, %4, %4\n v_xad_u32 %3, %3, %5, %5\n ")
+KERNEL(k_cmp_lt_u32, F32DECL, "v_cmp_lt_u32 vcc, %0, %4\n v_cmp_lt_u32 vcc, %1, %5\n v_cmp_lt_u32 vcc, %2, %4\n v_cmp_lt_u32 vcc, %3, %5\n ")
+KERNEL(k_sqrt_add_mix, F32DECL, "v_sqrt_f32 %0, %0\n v_add_f32 %0, %0, %4\n v_add_f32 %0, %0, %4\n v_add_f32 %0, %0, %4\n v_sqrt_f32 %1, %1\n v_add_f32 %1, %1, %5\n v_add_f32 %1, %1, %5\n v_add_f32 %1, %1, %5\n v_sqrt_f32 %2, %2\n v_add_f32 %2, %2, %4\n v_add_f32 %2, %2, %4\n v_add_f32 %2, %2, %4\n v_sqrt_f32 %3, %3\n v_add_f32 %3, %3, %5\n v_add_f32 %3, %3, %5\n v_add_f32 %3, %3, %5\n ")
+KERNEL(k_cmp_add_mix, F32DECL, "v_cmp_lt_f32 vcc, %0, %4\n v_add_f32 %0, %0, %4\n v_cmp_lt_f32 vcc, %1, %5\n v_add_f32 %1, %1, %5\n v_cmp_lt_f32 vcc, %2, %4\n v_add_f32 %2, %2, %4\n v_cmp_lt_f32 vcc, %3, %5\n v_add_f32 %3, %3, %5\n ")
+KERNEL(k_ldexp_f32, F32DECL, "v_ldexp_f32 %0, %0, %4\n v_ldexp_f32 %1, %1, %5\n v_ldexp_f32 %2, %2, %4\n v_ldexp_f32 %3, %3, %5\n ")
+KERNEL(k_frexp_mant, F32DECL, "v_frexp_mant_f32 %0, %0\n v_frexp_mant_f32 %1, %1\n v_frexp_mant_f32 %2, %2\n v_frexp_mant_f32 %3, %3\n ")
+
+KERNEL(m_cmp_add3, F32DECL, "v_cmp_lt_f32 vcc, %0, %4\n v_add_f32 %1, %1, %5\n v_add_f32 %2, %2, %4\n v_add_f32 %3, %3, %5\n")
+KERNEL(m_cmp2_add2, F32DECL, "v_cmp_lt_f32 vcc, %0, %4\n v_add_f32 %1, %1, %5\n v_cmp_lt_f32 vcc, %2, %4\n v_add_f32 %3, %3, %5\n")
+KERNEL(m_cmp3_add1, F32DECL, "v_cmp_lt_f32 vcc, %0, %4\n v_cmp_lt_f32 vcc, %1, %5\n v_cmp_lt_f32 vcc, %2, %4\n v_add_f32 %3, %3, %5\n")
+KERNEL(m_sqrt_add3, F32DECL, "v_sqrt_f32 %0, %0\n v_add_f32 %1, %1, %5\n v_add_f32 %2, %2, %4\n v_add_f32 %3, %3, %5\n")
+KERNEL(m_sqrt_cmp_add2, F32DECL, "v_sqrt_f32 %0, %0\n v_cmp_lt_f32 vcc, %1, %5\n v_add_f32 %2, %2, %4\n v_add_f32 %3, %3, %5\n")
+KERNEL(m_sqrt_cmp3, F32DECL, "v_sqrt_f32 %0, %0\n v_cmp_lt_f32 vcc, %1, %5\n v_cmp_lt_f32 vcc, %2, %4\n v_cmp_lt_f32 vcc, %3, %5\n")
+KERNEL(m_min_cnd_mul_fma, F32DECL, "v_min_f32 %0, %0, %4\n v_cndmask_b32 %1, %1, %5, vcc\n v_mul_f32 %2, %2, %4\n v_fma_f32 %3, %3, %5, %4\n")
+KERNEL(m_fma3_cmp, F32DECL, "v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %1, %1, %5, %4\n v_fma_f32 %2, %2, %4, %5\n v_cmp_lt_f32 vcc, %3, %5\n")
+KERNEL(m_min_add3, F32DECL, "v_min_f32 %0, %0, %4\n v_add_f32 %1, %1, %5\n v_mul_f32 %2, %2, %4\n v_add_f32 %3, %3, %5\n")
+KERNEL(m_cnd_add3, F32DECL, "v_cndmask_b32 %0, %0, %4, vcc\n v_add_f32 %1, %1, %5\n v_mul_f32 %2, %2, %4\n v_add_f32 %3, %3, %5\n")
+KERNEL(m_add_mul, F32DECL, "v_add_f32 %0, %0, %4\n v_mul_f32 %1, %1, %5\n v_add_f32 %2, %2, %4\n v_mul_f32 %3, %3, %5\n")
+
+
+// mixes of packed-f32 and scalar-f32 instructions (do the two pipes overlap?)
+#define MIXKERNEL(name, body)                                                       \
+	__global__ __launch_bounds__(256) void name(float *out, int reps) {             \
+		v2f p0 = {1.0f * threadIdx.x, 2.0f}, p1 = p0 + 1.0f, q0 = {1.0001f, 1.0f}, q1 = {0.9999f, 1.0f};   \
+		float a0 = threadIdx.x, a1 = a0 + 1, b0 = 1.0001f, b1 = 0.9999f;             \
+		for(int r = 0; r < reps; r++) {                                             \
+			asm volatile(body body body body body body body body                    \
+			             body body body body body body body body                    \
+			             : "+v"(p0), "+v"(p1), "+v"(a0), "+v"(a1) : "v"(q0), "v"(q1), "v"(b0), "v"(b1)); \
+		}                                                                           \
+		out[blockIdx.x * blockDim.x + threadIdx.x] = tof(p0) + tof(p1) + a0 + a1;   \
+	}
+MIXKERNEL(x_pk2_add2, "v_pk_mul_f32 %0, %0, %4\n v_add_f32 %2, %2, %6\n v_pk_mul_f32 %1, %1, %5\n v_add_f32 %3, %3, %7\n")
+MIXKERNEL(x_pk1_add3, "v_pk_mul_f32 %0, %0, %4\n v_add_f32 %2, %2, %6\n v_mul_f32 %3, %3, %7\n v_add_f32 %2, %2, %7\n")
+MIXKERNEL(x_pk3_add1, "v_pk_mul_f32 %0, %0, %4\n v_pk_add_f32 %1, %1, %5\n v_pk_mul_f32 %0, %0, %5\n v_add_f32 %3, %3, %7\n")
+MIXKERNEL(x_pk2_cmp2, "v_pk_mul_f32 %0, %0, %4\n v_cmp_lt_f32 vcc, %2, %6\n v_pk_mul_f32 %1, %1, %5\n v_cmp_lt_f32 vcc, %3, %7\n")
+MIXKERNEL(x_pkfma2_add2, "v_pk_fma_f32 %0, %0, %4, %5\n v_add_f32 %2, %2, %6\n v_pk_fma_f32 %1, %1, %5, %4\n v_add_f32 %3, %3, %7\n")
+MIXKERNEL(x_sqrt_pk3, "v_sqrt_f32 %2, %2\n v_pk_mul_f32 %0, %0, %4\n v_pk_add_f32 %1, %1, %5\n v_pk_mul_f32 %0, %0, %5\n")
+
 typedef void (*kfn)(float *, int);
 struct Entry { const char *name; kfn fn; };
 #define E(n) {#n, n}
@@ -81,7 +143,7 @@ struct Entry { const char *name; kfn fn; };
 int main(int argc, char **argv) {
 	Entry es[] = {E(k_mul_f32), E(k_fma_f32), E(k_sqrt_f32), E(k_rcp_f32), E(k_cndmask), E(k_cmp_f32), E(k_cmp_sgpr), E(k_min_f32),
 	              E(k_add_u32), E(k_mul_lo_u32), E(k_mul_hi_u32), E(k_cvt_f32_u32), E(k_mul_f64), E(k_fma_f64), E(k_mad_u64_u32),
-	              E(k_cvt_f64_u32), E(k_cvt_f32_f64), E(k_pk_mul_f32), E(k_pk_add_f32), E(k_pk_fma_f32), E(k_readlane), E(k_salu), E(k_cndmask_nodep), E(k_cndmask_sgpr), E(k_cmp_cnd_pair), E(k_add_f32), E(k_max_f32), E(k_and_b32), E(k_mov_b32), E(k_lshl_add), E(k_min_u32), E(k_min3_f32), E(k_med3_f32), E(k_mul_legacy), E(k_rsq_f32), E(k_div_scale), E(k_div_fmas), E(k_div_fixup), E(k_cmp_class), E(k_mul_sgpr), E(k_fma_sgpr), E(k_sub_sgpr)};
+	              E(k_cvt_f64_u32), E(k_cvt_f32_f64), E(k_pk_mul_f32), E(k_pk_add_f32), E(k_pk_fma_f32), E(k_readlane), E(k_salu), E(k_cndmask_nodep), E(k_cndmask_sgpr), E(k_cmp_cnd_pair), E(k_add_f32), E(k_max_f32), E(k_and_b32), E(k_mov_b32), E(k_lshl_add), E(k_min_u32), E(k_min3_f32), E(k_med3_f32), E(k_mul_legacy), E(k_rsq_f32), E(k_div_scale), E(k_div_fmas), E(k_div_fixup), E(k_cmp_class), E(k_mul_sgpr), E(k_fma_sgpr), E(k_sub_sgpr), E(x_pk2_add2), E(x_pk1_add3), E(x_pk3_add1), E(x_pk2_cmp2), E(x_pkfma2_add2), E(x_sqrt_pk3), E(m_cmp_add3), E(m_cmp2_add2), E(m_cmp3_add1), E(m_sqrt_add3), E(m_sqrt_cmp_add2), E(m_sqrt_cmp3), E(m_min_cnd_mul_fma), E(m_fma3_cmp), E(m_min_add3), E(m_cnd_add3), E(m_add_mul), E(k_ashr_i32), E(k_lshr_b32), E(k_lshl_b32), E(k_sub_u32), E(k_xor_b32), E(k_or_b32), E(k_bfe_u32), E(k_add3_u32), E(k_and_or_b32), E(k_fmac_f32), E(k_add_f32_neg), E(k_sub_f32), E(k_add_f32_abs), E(k_addc_co), E(k_subb_co), E(k_add_co), E(k_max_u32), E(k_med3_u32), E(k_min_i32), E(k_bfi_b32), E(k_perm_b32), E(k_mul_u32_u24), E(k_mad_u32_u24), E(k_xad_u32), E(k_cmp_lt_u32), E(k_sqrt_add_mix), E(k_cmp_add_mix), E(k_ldexp_f32), E(k_frexp_mant)};
 	int wavesPerSimd = argc > 1 ? atoi(argv[1]) : 8;
 	int blocks = 256 * wavesPerSimd;   // 256 CUs x (wavesPerSimd*4 waves / 4 waves per block)
 	float *out;
