@@ -147,12 +147,13 @@ PT_DEV float pow5(float x) {
 	return (float)(d4 * d);
 }
 
-// src/cl/ray.cl:58-62 — Schlick
-PT_DEV float reflectance(float cosTheta, float rel) {
+// src/cl/ray.cl:58-62 — Schlick, in two parts: r0 depends on the material only (for a front-face hit rel is the
+// sphere's refIdx, and the host folds the same four IEEE operations into the material table once)
+PT_DEV float schlick_r0(float rel) {
 	float r = pt_div(1.0f - rel, 1.0f + rel);
-	r = r * r;
-	return r + (1.0f - r) * pow5(1.0f - cosTheta);
+	return r * r;
 }
+PT_DEV float reflectance(float cosTheta, float r0) { return r0 + (1.0f - r0) * pow5(1.0f - cosTheta); }
 
 // src/cl/ray.cl:64-69
 PT_DEV f3 refraction_dir(f3 in, f3 n, float rel) {

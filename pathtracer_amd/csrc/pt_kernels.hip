@@ -69,7 +69,7 @@ __global__ void pt_selftest_kernel(int op, const uint64_t *a, const uint64_t *b,
 		float x = inf_[2 * i], y = inf_[2 * i + 1];
 		of[4 * i] = x / y;
 		of[4 * i + 1] = sqrtf(x);
-		of[4 * i + 2] = reflectance(x, y);
+		of[4 * i + 2] = reflectance(x, schlick_r0(y));
 		of[4 * i + 3] = pow5(x);
 	} else if(op == 4) {
 		// bit patterns a[i] .. a[i] + b[i] - 1: how many have sqrt_cr != sqrtf, how many in sqrt_nt's
@@ -229,7 +229,11 @@ extern "C" int pt_scene_upload(pt_ctx *c, const float *spheres, int n) {
 		float tb;
 		memcpy(&tb, &type, 4);
 		ha[i] = make_float4(r[5], r[6], r[7], tb);
-		hb[i] = make_float4(r[8], r[9], r[10], 0.0f);
+		// Schlick r0 of a front-face hit, ((1 - refIdx) / (1 + refIdx))^2 (src/cl/ray.cl:59-60 with rel = refIdx):
+		// the same four correctly rounded binary32 operations the kernel would repeat per hit
+		volatile float q = (1.0f - r[10]) / (1.0f + r[10]);
+		volatile float r0 = q * q;
+		hb[i] = make_float4(r[8], r[9], r[10], r0);
 	}
 	// one stream, in order; the staging buffer is freed after the copies have completed
 	hipError_t e1 = hipMemcpyAsync(c->geom, hg, sizeof(float4) * (size_t)n, hipMemcpyHostToDevice, c->stream);
@@ -460,7 +464,7 @@ extern "C" int pt_render(pt_ctx *c, const pt_render_args *a) {
 		la.grid = c->grid;
 		la.kernel = PT_K_GRID;
 	}
-	la.ldsBytes = la.kernel == PT_K_LDS ? 3 * sizeof(float4) * (size_t)c->nSpheres : 0;
+	la.ldsBytes = la.kernel == PT_K_LDS ? sizeof(float4) * (3 * (size_t)c->nSpheres + (size_t)c->nSpheres / 3) : 0;   // tables + index trios
 	// streaming kernel: persistent one-wave blocks, at most 32 per CU; surplus pixels come through the queue
 	const long long swaves = (lp + 63) / 64;
 	la.gridStream = (unsigned)(swaves < 256 * 32 ? swaves : 256 * 32);

@@ -25,7 +25,7 @@ struct KParams {
 };
 
 // Device scene tables (SoA).  geom[i] = {cx, cy, cz, r*r}; matA[i] = {colr, colg, colb, type bits};
-// matB[i] = {tint, fuzz, refIdx, 0}.
+// matB[i] = {tint, fuzz, refIdx, ((1 - refIdx) / (1 + refIdx))^2}.
 struct SceneTables {
 	const float4 *geom;
 	const float4 *matA;

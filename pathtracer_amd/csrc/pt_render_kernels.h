@@ -86,11 +86,12 @@ PT_DEV bool shade_hit(Path &pt, float t, const float4 g, const float4 mA, const 
 		mask = add3(scl3(pt.mask, 1.0f - mB.x), scl3(mask, mB.x));                       // ray.cl:147,170
 		if(type == 2) base = reflection_dir(d, normal);                                  // ray.cl:145
 		else {                                                                           // ray.cl:150-171
-			const float rel = front ? mB.z : pt_div(1.0f, mB.z);
+			float rel = mB.z, r0 = mB.w;                                                 // mB.w: Schlick r0 of refIdx, folded on the host
+			if(!front) { rel = pt_div(1.0f, mB.z); r0 = schlick_r0(rel); }               // ray.cl:152
 			const float cosTheta = fminf(dot3(scl3(d, -1.0f), normal), 1.0f);
 			const float sinTheta = sqrt_cr(1.0f - cosTheta * cosTheta);
 			bool reflect = rel * sinTheta > 1.0f;
-			if(!reflect) reflect = reflectance(cosTheta, rel) > rand_float(pt.rng);      // short-circuit draw, ray.cl:163
+			if(!reflect) reflect = reflectance(cosTheta, r0) > rand_float(pt.rng);      // short-circuit draw, ray.cl:163
 			base = reflect ? reflection_dir(d, normal) : refraction_dir(d, normal, rel);
 		}
 	}
@@ -151,7 +152,20 @@ PT_DEV void sphere_disc(const float4 g, f3 o, f3 d, float a, float &bHalf, float
 	disc = bHalf * bHalf - a * c;
 }
 
-PT_DEV void candidate_update(float bHalf, float disc, int i, uint32_t &best, uint32_t &prev, int &idx, float &tiny) {
+// smallest |disc| seen, as one v_min_f32 with the |x| source modifier (fminf(fabsf()) costs two extra
+// canonicalising v_max); a NaN disc leaves it unchanged
+PT_DEV void track_tiny(float disc, float &tiny) {
+#if !PT_FAST_MATH
+	asm("v_min_f32 %0, %0, |%1|" : "+v"(tiny) : "v"(disc));
+#endif
+}
+PT_DEV void track_tiny2(float discA, float discB, float &tiny) {
+#if !PT_FAST_MATH
+	asm("v_min3_f32 %0, %0, |%1|, |%2|" : "+v"(tiny) : "v"(discA), "v"(discB));
+#endif
+}
+
+PT_DEV void candidate_key(float bHalf, float disc, int i, uint32_t &best, uint32_t &prev, int &idx) {
 #if PT_FAST_MATH
 	// relaxed build: no tie or small-disc bookkeeping; num == +0 (t == 0, no hit) is kept out by the -1
 	const float numf = -bHalf - __builtin_amdgcn_sqrtf(disc);
@@ -161,15 +175,17 @@ PT_DEV void candidate_update(float bHalf, float disc, int i, uint32_t &best, uin
 	best = updf ? keyf : best;
 	return;
 #endif
-	// smallest |disc| seen, as one v_min_f32 with the |x| source modifier (fminf(fabsf()) costs two extra
-	// canonicalising v_max); a NaN disc leaves it unchanged
-	asm("v_min_f32 %0, %0, |%1|" : "+v"(tiny) : "v"(disc));
 	const float num = -bHalf - sqrt_nt(disc);
 	const uint32_t key = __float_as_uint(num);
 	const bool upd = key < best;
 	prev = upd ? best : prev;
 	idx = upd ? i : idx;
 	best = upd ? key : best;
+}
+
+PT_DEV void candidate_update(float bHalf, float disc, int i, uint32_t &best, uint32_t &prev, int &idx, float &tiny) {
+	track_tiny(disc, tiny);
+	candidate_key(bHalf, disc, i, best, prev, idx);
 }
 
 PT_DEV void test_sphere(const float4 g, int i, f3 o, f3 d, float a, uint32_t &best, uint32_t &prev, int &idx, float &tiny) {
@@ -258,17 +274,27 @@ PT_DEV Hit closest_hit_wave(const float4 *__restrict__ geom, int n, f3 o, f3 d, 
 	return h;
 }
 
+// Scan of a table staged whole in LDS, three spheres per trip.  `trio[t]` = {3t, 3t+1, 3t+2, -}: the sphere indices
+// arrive in VGPRs through the (otherwise idle) LDS pipe instead of one v_mov from the scalar loop counter per
+// sphere — the kernel is bound by the number of VALU instructions issued (profiles/r01_ubench_valu_issue_cost.md).
 template <typename Tab>
-PT_DEV Hit closest_hit(const Tab geom, int n, f3 o, f3 d, float a) {
+PT_DEV Hit closest_hit(const Tab geom, const int4 *trio, int n, f3 o, f3 d, float a) {
 	uint32_t best = KEY_NONE, prev = KEY_NONE;
 	float tiny = __builtin_inff();
 	int idx = 0;
 	int i = 0;
-	for(; i + 3 <= n; i += 3) {
+	for(int t = 0; i + 3 <= n; i += 3, t++) {
 		const float4 g0 = geom[i], g1 = geom[i + 1], g2 = geom[i + 2];
-		test_sphere(g0, i, o, d, a, best, prev, idx, tiny);
-		test_sphere(g1, i + 1, o, d, a, best, prev, idx, tiny);
-		test_sphere(g2, i + 2, o, d, a, best, prev, idx, tiny);
+		const int4 ii = trio[t];
+		float b0, b1, b2, d0, d1, d2;
+		sphere_disc(g0, o, d, a, b0, d0);
+		sphere_disc(g1, o, d, a, b1, d1);
+		sphere_disc(g2, o, d, a, b2, d2);
+		track_tiny2(d0, d1, tiny);
+		track_tiny(d2, tiny);
+		candidate_key(b0, d0, ii.x, best, prev, idx);
+		candidate_key(b1, d1, ii.y, best, prev, idx);
+		candidate_key(b2, d2, ii.z, best, prev, idx);
 	}
 	for(; i < n; i++) test_sphere(geom[i], i, o, d, a, best, prev, idx, tiny);
 	return finish_hit(geom, n, o, d, a, best, prev, idx, tiny);
@@ -286,10 +312,12 @@ __global__ __launch_bounds__(256) void pt_render_lds_kernel(float4 *__restrict__
                                                              unsigned long long *__restrict__ bounceCounter) {
 	extern __shared__ float4 lds[];
 	float4 *const sGeom = lds, *const sMatA = lds + p.n, *const sMatB = lds + 2 * p.n;
+	int4 *const sTrio = (int4 *)(lds + 3 * p.n);           // p.n / 3 entries (closest_hit)
 	for(int i = (int)threadIdx.x; i < p.n; i += (int)blockDim.x) {
 		sGeom[i] = sc.geom[i];
 		sMatA[i] = sc.matA[i];
 		sMatB[i] = sc.matB[i];
+		if(i % 3 == 0 && i + 3 <= p.n) sTrio[i / 3] = make_int4(i, i + 1, i + 2, 0);
 	}
 	__syncthreads();
 	// Sample-interleaved lanes: a pixel is served by S = 1 << p.logS adjacent lanes, lane `sub` tracing the
@@ -322,7 +350,7 @@ __global__ __launch_bounds__(256) void pt_render_lds_kernel(float4 *__restrict__
 					if(COUNT) myBounces++;
 					const float ln = len3(pt.d);
 					const float a = ln * ln;                                             // ray.cl:73 pow(length(d),2)
-					const Hit h = closest_hit(sGeom, p.n, pt.o, pt.d, a);
+					const Hit h = closest_hit(sGeom, sTrio, p.n, pt.o, pt.d, a);
 					if(!h.hit) { color = mul3(pt.mask, mk3(p.bgx, p.bgy, p.bgz)); break; }   // ray.cl:112-115
 					if(shade_hit(pt, h.t, sGeom[h.idx], sMatA[h.idx], sMatB[h.idx], color)) break;
 				}
