@@ -71,21 +71,37 @@ PT_DEV float sqrt_cr(float x) {
 
 PT_DEV float len3(f3 a) { return sqrt_cr(dot3(a, a)); }
 
-// 1.0f / x for the normalisations: v_rcp_f32 (1 ulp) and two FMA Newton steps, which land on the correctly
-// rounded quotient for every x with 2^-126 <= |x| <= 2^126 (pt_selftest op 5 checks all of them against the
-// compiler's correctly rounded divide); outside (0, denormals, huge, inf, NaN) the full divide is used.
-PT_DEV float rcp_cr(float x) {
-#if PT_FAST_MATH
-	return __builtin_amdgcn_rcpf(x);
-#endif
+// 1.0f / x: v_rcp_f32 (1 ulp) and two FMA Newton steps, which land on the correctly rounded quotient for every x
+// with 2^-126 <= |x| <= 2^126 (pt_selftest op 5 checks all of them against the compiler's correctly rounded
+// divide).  rcp_nt is the bare sequence for callers that know x is in that range; rcp_cr adds the guard that sends
+// everything else (0, denormals, huge, inf, NaN) to the full divide.
+PT_DEV float rcp_nt(float x) {
 	float r = __builtin_amdgcn_rcpf(x);
+#if !PT_FAST_MATH
 	r = __builtin_fmaf(__builtin_fmaf(-x, r, 1.0f), r, r);
 	r = __builtin_fmaf(__builtin_fmaf(-x, r, 1.0f), r, r);
+#endif
+	return r;
+}
+PT_DEV float rcp_cr(float x) {
+	float r = rcp_nt(x);
+#if !PT_FAST_MATH
 	if(__builtin_expect((__float_as_uint(x) & 0x7fffffffu) - 0x00800000u > 0x7e800000u - 0x00800000u, 0)) r = 1.0f / x;
+#endif
 	return r;
 }
 
-PT_DEV f3 norm3(f3 a) { float inv = rcp_cr(len3(a)); return scl3(a, inv); }
+// normalize() = a * (1 / length(a)) (oracle/ref_shim.cpp): the short sqrt and the short reciprocal under ONE guard.
+// x = dot(a, a) in [2^-96, 2^127] puts sqrt_nt in its exact domain and the length in [2^-48, 2^63.5], well inside
+// rcp_nt's; everything else (0, tiny, huge, inf, NaN) takes the compiler's correctly rounded forms.
+PT_DEV f3 norm3(f3 a) {
+	const float x = dot3(a, a);
+	float inv = rcp_nt(sqrt_nt(x));
+#if !PT_FAST_MATH
+	if(__builtin_expect(__float_as_uint(x) - PT_SQRT_TINY_BITS > 0x7f000000u - PT_SQRT_TINY_BITS, 0)) inv = 1.0f / sqrtf(x);
+#endif
+	return scl3(a, inv);
+}
 
 constexpr uint32_t PT_M31 = 2147483647u;   // MINSTD modulus 2^31 - 1 (src/cl/rng.cl:12)
 
@@ -160,7 +176,7 @@ PT_DEV f3 refraction_dir(f3 in, f3 n, float rel) {
 	float cosTheta = fminf(dot3(scl3(in, -1.0f), n), 1.0f);
 	f3 perp = scl3(add3(in, scl3(n, cosTheta)), rel);
 	float lp = len3(perp);
-	f3 par = scl3(n, -sqrt_cr(fabsf(1.0f - lp * lp)));
+	f3 par = scl3(n, -sqrt_nt(fabsf(1.0f - lp * lp)));      // 1 - lp*lp is 0 or at least 2^-24 in magnitude: sqrt_nt is exact
 	return add3(par, perp);
 }
 

@@ -464,7 +464,7 @@ extern "C" int pt_render(pt_ctx *c, const pt_render_args *a) {
 		la.grid = c->grid;
 		la.kernel = PT_K_GRID;
 	}
-	la.ldsBytes = la.kernel == PT_K_LDS ? sizeof(float4) * (3 * (size_t)c->nSpheres + (size_t)c->nSpheres / 3) : 0;   // tables + index trios
+	la.ldsBytes = la.kernel == PT_K_LDS ? pt_strict::lds_table_bytes(c->nSpheres) : 0;
 	// streaming kernel: persistent one-wave blocks, at most 32 per CU; surplus pixels come through the queue
 	const long long swaves = (lp + 63) / 64;
 	la.gridStream = (unsigned)(swaves < 256 * 32 ? swaves : 256 * 32);

@@ -89,7 +89,7 @@ PT_DEV bool shade_hit(Path &pt, float t, const float4 g, const float4 mA, const 
 			float rel = mB.z, r0 = mB.w;                                                 // mB.w: Schlick r0 of refIdx, folded on the host
 			if(!front) { rel = pt_div(1.0f, mB.z); r0 = schlick_r0(rel); }               // ray.cl:152
 			const float cosTheta = fminf(dot3(scl3(d, -1.0f), normal), 1.0f);
-			const float sinTheta = sqrt_cr(1.0f - cosTheta * cosTheta);
+			const float sinTheta = sqrt_nt(1.0f - cosTheta * cosTheta);                   // 0, or at least 2^-24 in magnitude (negative: NaN, as sqrtf)
 			bool reflect = rel * sinTheta > 1.0f;
 			if(!reflect) reflect = reflectance(cosTheta, r0) > rand_float(pt.rng);      // short-circuit draw, ray.cl:163
 			base = reflect ? reflection_dir(d, normal) : refraction_dir(d, normal, rel);
@@ -274,18 +274,50 @@ PT_DEV Hit closest_hit_wave(const float4 *__restrict__ geom, int n, f3 o, f3 d, 
 	return h;
 }
 
-// Scan of a table staged whole in LDS, three spheres per trip.  `trio[t]` = {3t, 3t+1, 3t+2, -}: the sphere indices
-// arrive in VGPRs through the (otherwise idle) LDS pipe instead of one v_mov from the scalar loop counter per
-// sphere — the kernel is bound by the number of VALU instructions issued (profiles/r01_ubench_valu_issue_cost.md).
-template <typename Tab>
-PT_DEV Hit closest_hit(const Tab geom, const int4 *trio, int n, f3 o, f3 d, float a) {
+// LDS image of the tables for the lock-step kernel: one 48-byte record {geom, matA, matB} per sphere, three records
+// and one int4 of their LDS addresses per 160-byte trio, the n % 3 last records after the trios:
+//   trio t at 160 t:  record 3t | record 3t+1 | record 3t+2 | {addr(3t), addr(3t+1), addr(3t+2), -}
+// The scan walks it with ONE address register per trip and constant offsets; the winner is tracked by its record
+// address, which arrives in a VGPR through the (otherwise idle) LDS pipe instead of a v_mov from the scalar loop
+// counter per sphere, and the shading reads geometry and materials at that address + 0/16/32 with no address
+// arithmetic.  The kernel is bound by the number of VALU instructions issued (profiles/r01_ubench_valu_issue_cost.md).
+#define PT_REC_BYTES 48
+#define PT_TRIO_BYTES 160
+typedef float pt_v4f __attribute__((ext_vector_type(4)));
+typedef int pt_v4i __attribute__((ext_vector_type(4)));
+// ds_read_b128 at a 32-bit LDS address (+ a constant offset the compiler folds into the instruction)
+PT_DEV float4 lds_f4(uint32_t addr) {
+	const pt_v4f v = *(const __attribute__((address_space(3))) pt_v4f *)(uintptr_t)addr;
+	return make_float4(v.x, v.y, v.z, v.w);
+}
+PT_DEV int4 lds_i4(uint32_t addr) {
+	const pt_v4i v = *(const __attribute__((address_space(3))) pt_v4i *)(uintptr_t)addr;
+	return make_int4(v.x, v.y, v.z, v.w);
+}
+
+PT_DEV uint32_t lds_record_offset(int i) {
+	const int t = i / 3;
+	return (uint32_t)(PT_TRIO_BYTES * t + PT_REC_BYTES * (i - 3 * t));
+}
+inline size_t lds_table_bytes(int n) { return (size_t)PT_TRIO_BYTES * (size_t)(n / 3) + (size_t)PT_REC_BYTES * (size_t)(n % 3); }
+
+struct LdsGeom {      // geom[i] for closest_hit_reference
+	uint32_t base;
+	PT_DEV float4 operator[](int i) const { return lds_f4(base + lds_record_offset(i)); }
+};
+
+// Returns Hit.idx = LDS address of the winner's record.  `a` may be wrong when dot(d, d) < 2^-96 (the caller uses
+// the unguarded sqrt_nt); it is then below 2^-40, finish_scan() asks for the reference scan, and that gets the
+// exact value.
+PT_DEV Hit closest_hit_lds(uint32_t base, int n, f3 o, f3 d, float a) {
 	uint32_t best = KEY_NONE, prev = KEY_NONE;
 	float tiny = __builtin_inff();
 	int idx = 0;
+	uint32_t addr = base;
 	int i = 0;
-	for(int t = 0; i + 3 <= n; i += 3, t++) {
-		const float4 g0 = geom[i], g1 = geom[i + 1], g2 = geom[i + 2];
-		const int4 ii = trio[t];
+	for(; i + 3 <= n; i += 3, addr += PT_TRIO_BYTES) {
+		const float4 g0 = lds_f4(addr), g1 = lds_f4(addr + PT_REC_BYTES), g2 = lds_f4(addr + 2 * PT_REC_BYTES);
+		const int4 ii = lds_i4(addr + 3 * PT_REC_BYTES);
 		float b0, b1, b2, d0, d1, d2;
 		sphere_disc(g0, o, d, a, b0, d0);
 		sphere_disc(g1, o, d, a, b1, d1);
@@ -296,8 +328,16 @@ PT_DEV Hit closest_hit(const Tab geom, const int4 *trio, int n, f3 o, f3 d, floa
 		candidate_key(b1, d1, ii.y, best, prev, idx);
 		candidate_key(b2, d2, ii.z, best, prev, idx);
 	}
-	for(; i < n; i++) test_sphere(geom[i], i, o, d, a, best, prev, idx, tiny);
-	return finish_hit(geom, n, o, d, a, best, prev, idx, tiny);
+	for(; i < n; i++, addr += PT_REC_BYTES) test_sphere(lds_f4(addr), (int)addr, o, d, a, best, prev, idx, tiny);
+	bool slow;
+	Hit h = finish_scan(a, best, prev, idx, tiny, slow);
+	if(__builtin_expect(slow, 0)) {
+		const float ln = len3(d);
+		const LdsGeom tab = {base};
+		h = closest_hit_reference(tab, n, o, d, ln * ln);
+		h.idx = (int)(base + lds_record_offset(h.idx));
+	}
+	return h;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -311,13 +351,17 @@ __global__ __launch_bounds__(256) void pt_render_lds_kernel(float4 *__restrict__
                                                              const uint64_t *__restrict__ seedmul,
                                                              unsigned long long *__restrict__ bounceCounter) {
 	extern __shared__ float4 lds[];
-	float4 *const sGeom = lds, *const sMatA = lds + p.n, *const sMatB = lds + 2 * p.n;
-	int4 *const sTrio = (int4 *)(lds + 3 * p.n);           // p.n / 3 entries (closest_hit)
+	const uint32_t ldsBase = (uint32_t)(uintptr_t)lds;      // low half of the flat address = LDS address
 	for(int i = (int)threadIdx.x; i < p.n; i += (int)blockDim.x) {
-		sGeom[i] = sc.geom[i];
-		sMatA[i] = sc.matA[i];
-		sMatB[i] = sc.matB[i];
-		if(i % 3 == 0 && i + 3 <= p.n) sTrio[i / 3] = make_int4(i, i + 1, i + 2, 0);
+		const uint32_t off = lds_record_offset(i);
+		float4 *const rec = (float4 *)((char *)lds + off);
+		rec[0] = sc.geom[i];
+		rec[1] = sc.matA[i];
+		rec[2] = sc.matB[i];
+		if(i % 3 == 0 && i + 3 <= p.n) {
+			const int a0 = (int)(ldsBase + off);
+			*(int4 *)((char *)lds + off + 3 * PT_REC_BYTES) = make_int4(a0, a0 + PT_REC_BYTES, a0 + 2 * PT_REC_BYTES, 0);
+		}
 	}
 	__syncthreads();
 	// Sample-interleaved lanes: a pixel is served by S = 1 << p.logS adjacent lanes, lane `sub` tracing the
@@ -348,11 +392,12 @@ __global__ __launch_bounds__(256) void pt_render_lds_kernel(float4 *__restrict__
 				start_sample(pt, p, id, origin, seedmul[k]);
 				for(int j = 0; j < p.maxDepth; j++) {                                    // ray.cl:96
 					if(COUNT) myBounces++;
-					const float ln = len3(pt.d);
+					const float ln = sqrt_nt(dot3(pt.d, pt.d));                          // see closest_hit_lds()
 					const float a = ln * ln;                                             // ray.cl:73 pow(length(d),2)
-					const Hit h = closest_hit(sGeom, sTrio, p.n, pt.o, pt.d, a);
+					const Hit h = closest_hit_lds(ldsBase, p.n, pt.o, pt.d, a);
 					if(!h.hit) { color = mul3(pt.mask, mk3(p.bgx, p.bgy, p.bgz)); break; }   // ray.cl:112-115
-					if(shade_hit(pt, h.t, sGeom[h.idx], sMatA[h.idx], sMatB[h.idx], color)) break;
+					const uint32_t rec = (uint32_t)h.idx;
+					if(shade_hit(pt, h.t, lds_f4(rec), lds_f4(rec + 16), lds_f4(rec + 32), color)) break;
 				}
 			}
 			if(S == 1) acc = accumulate(acc, color, p, p.firstFrame + k0);
