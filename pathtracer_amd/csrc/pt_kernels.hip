@@ -95,6 +95,19 @@ __global__ void pt_selftest_kernel(int op, const uint64_t *a, const uint64_t *b,
 			if(want != want ? (got == got) : (__float_as_uint(got) != __float_as_uint(want))) bad++;
 		}
 		ou[i] = bad;
+	} else if(op == 6) {
+		// bit patterns a[i] .. a[i] + b[i] - 1 (positive normal floats >= 2^-96): how often is raw v_sqrt_f32 one ulp
+		// above (low half) / one ulp below (high half) the correctly rounded result
+		uint64_t hi = 0, lo = 0;
+		for(uint64_t k = 0; k < b[i]; k++) {
+			const uint32_t u = (uint32_t)(a[i] + k);
+			if(u < PT_SQRT_TINY_BITS || u >= 0x7f800000u) continue;
+			const float x = __uint_as_float(u);
+			const uint32_t want = __float_as_uint(sqrtf(x)), raw = __float_as_uint(__builtin_amdgcn_sqrtf(x));
+			if(raw > want) hi++;
+			if(raw < want) lo++;
+		}
+		ou[i] = hi + (lo << 32);
 	}
 }
 
@@ -440,6 +453,15 @@ extern "C" int pt_render(pt_ctx *c, const pt_render_args *a) {
 		else while(want < 3 && (lp << want) < 64ll * 12 * 8192 && (2 << want) <= a->n_frames) want++;
 		p.logS = want;
 	}
+	// LDS kernel: trios of the table that hold a sphere much smaller than the largest one get a wave-level "can any
+	// lane hit it" test per sphere before the sqrt/select part (closest_hit_lds); a pure speed heuristic, same image.
+	p.trioSkipMask = 0;
+	if(c->hostSpheres && !getenv("PT_NO_TRIO_SKIP")) {
+		float rmax = 0.0f;
+		for(int i = 0; i < c->nSpheres; i++) rmax = fmaxf(rmax, fabsf(c->hostSpheres[i].w));
+		for(int i = 0; i < c->nSpheres && i < 96 && i / 3 < c->nSpheres / 3; i++)
+			if(fabsf(c->hostSpheres[i].w) < rmax * 0.125f) p.trioSkipMask |= 1u << (i / 3);
+	}
 	LaunchArgs la;
 	la.image = img; la.p = p; la.sc = sc; la.seedmul = c->seedmul; la.bounceCounter = c->counter; la.queue = c->queue;
 	la.stream = st; la.count = a->bounce_count != NULL;
@@ -556,7 +578,7 @@ extern "C" int pt_image_read_u8(pt_ctx *c, const void *d_image, int width, int h
 
 extern "C" int pt_selftest(pt_ctx *c, int op, const uint64_t *a, const uint64_t *b, const float *in_f, int n,
                            uint64_t *out_u64, float *out_f) {
-	if(!c || n <= 0 || op < 0 || op > 5) return fail(PT_E_INVALID, "pt_selftest: bad arguments%s", NULL);
+	if(!c || n <= 0 || op < 0 || op > 6) return fail(PT_E_INVALID, "pt_selftest: bad arguments%s", NULL);
 	HIP_TRY(hipSetDevice(c->device));
 	uint64_t *da = NULL, *db = NULL, *dou = NULL;
 	float *dif = NULL, *dof = NULL;

@@ -22,6 +22,7 @@ struct KParams {
 	int rank, world, bandRows;          // row-band partition (pt_hip.h)
 	int localPixels;                    // pixels of this rank
 	int logS;                           // LDS kernel: 2^logS lanes share a pixel (sample-interleaved)
+	unsigned trioSkipMask;              // LDS kernel: bit t = trio t of the table holds a small sphere (closest_hit_lds)
 };
 
 // Device scene tables (SoA).  geom[i] = {cx, cy, cz, r*r}; matA[i] = {colr, colg, colb, type bits};

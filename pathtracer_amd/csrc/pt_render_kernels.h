@@ -309,7 +309,19 @@ struct LdsGeom {      // geom[i] for closest_hit_reference
 // Returns Hit.idx = LDS address of the winner's record.  `a` may be wrong when dot(d, d) < 2^-96 (the caller uses
 // the unguarded sqrt_nt); it is then below 2^-40, finish_scan() asks for the reference scan, and that gets the
 // exact value.
-PT_DEV Hit closest_hit_lds(uint32_t base, int n, f3 o, f3 d, float a) {
+// Wave-level "can any lane hit this sphere": a hit needs disc >= 0 and bHalf < 0 (then -bHalf > sqrt(disc) is
+// possible); min(disc, -bHalf) >= 0 is a superset of that, and what it rules out is no hit in the reference either
+// (disc < 0: ray.cl:78; bHalf >= 0: t <= 0, ray.cl:82).  One v_min with a source modifier, one compare, one scalar branch.
+PT_DEV bool wave_can_hit(float disc, float bHalf) {
+	float m;
+	asm("v_min_f32 %0, %1, -%2" : "=v"(m) : "v"(disc), "v"(bHalf));
+	return __builtin_amdgcn_ballot_w64(m >= 0.0f) != 0;
+}
+
+// `skipMask` bit t: trio t holds a sphere much smaller than the largest of the table (set by the host); such a sphere
+// is rarely a candidate for any of the 64 rays of a wave, and its sqrt/select part is entered only if it is.
+template <bool SKIP>
+PT_DEV Hit closest_hit_lds(uint32_t base, int n, unsigned skipMask, f3 o, f3 d, float a) {
 	uint32_t best = KEY_NONE, prev = KEY_NONE;
 	float tiny = __builtin_inff();
 	int idx = 0;
@@ -322,11 +334,18 @@ PT_DEV Hit closest_hit_lds(uint32_t base, int n, f3 o, f3 d, float a) {
 		sphere_disc(g0, o, d, a, b0, d0);
 		sphere_disc(g1, o, d, a, b1, d1);
 		sphere_disc(g2, o, d, a, b2, d2);
-		track_tiny2(d0, d1, tiny);
-		track_tiny(d2, tiny);
-		candidate_key(b0, d0, ii.x, best, prev, idx);
-		candidate_key(b1, d1, ii.y, best, prev, idx);
-		candidate_key(b2, d2, ii.z, best, prev, idx);
+		if(SKIP && (skipMask & 1u)) {
+			if(wave_can_hit(d0, b0)) candidate_update(b0, d0, ii.x, best, prev, idx, tiny);
+			if(wave_can_hit(d1, b1)) candidate_update(b1, d1, ii.y, best, prev, idx, tiny);
+			if(wave_can_hit(d2, b2)) candidate_update(b2, d2, ii.z, best, prev, idx, tiny);
+		} else {
+			track_tiny2(d0, d1, tiny);
+			track_tiny(d2, tiny);
+			candidate_key(b0, d0, ii.x, best, prev, idx);
+			candidate_key(b1, d1, ii.y, best, prev, idx);
+			candidate_key(b2, d2, ii.z, best, prev, idx);
+		}
+		if(SKIP) skipMask >>= 1;
 	}
 	for(; i < n; i++, addr += PT_REC_BYTES) test_sphere(lds_f4(addr), (int)addr, o, d, a, best, prev, idx, tiny);
 	bool slow;
@@ -346,7 +365,7 @@ PT_DEV Hit closest_hit_lds(uint32_t base, int n, f3 o, f3 d, float a) {
 // wave-uniform (geometry) or per-lane (material of the winning sphere) ds_reads, so the
 // arithmetic runs on VGPR operands at full VALU rate.
 // ---------------------------------------------------------------------------------------
-template <bool COUNT>
+template <bool COUNT, bool SKIP>
 __global__ __launch_bounds__(256) void pt_render_lds_kernel(float4 *__restrict__ image, const KParams p, const SceneTables sc,
                                                              const uint64_t *__restrict__ seedmul,
                                                              unsigned long long *__restrict__ bounceCounter) {
@@ -394,7 +413,7 @@ __global__ __launch_bounds__(256) void pt_render_lds_kernel(float4 *__restrict__
 					if(COUNT) myBounces++;
 					const float ln = sqrt_nt(dot3(pt.d, pt.d));                          // see closest_hit_lds()
 					const float a = ln * ln;                                             // ray.cl:73 pow(length(d),2)
-					const Hit h = closest_hit_lds(ldsBase, p.n, pt.o, pt.d, a);
+					const Hit h = closest_hit_lds<SKIP>(ldsBase, p.n, p.trioSkipMask, pt.o, pt.d, a);
 					if(!h.hit) { color = mul3(pt.mask, mk3(p.bgx, p.bgy, p.bgz)); break; }   // ray.cl:112-115
 					const uint32_t rec = (uint32_t)h.idx;
 					if(shade_hit(pt, h.t, lds_f4(rec), lds_f4(rec + 16), lds_f4(rec + 32), color)) break;
@@ -679,8 +698,11 @@ __global__ __launch_bounds__(64) void pt_render_stream_kernel(float4 *__restrict
 void launch_render(const LaunchArgs &la) {
 	const dim3 block(256), grid(la.gridPixels), sgrid(la.gridStream);
 	if(la.kernel == PT_K_LDS) {
-		if(la.count) hipLaunchKernelGGL(pt_render_lds_kernel<true>, grid, block, la.ldsBytes, la.stream, la.image, la.p, la.sc, la.seedmul, la.bounceCounter);
-		else hipLaunchKernelGGL(pt_render_lds_kernel<false>, grid, block, la.ldsBytes, la.stream, la.image, la.p, la.sc, la.seedmul, la.bounceCounter);
+		// four instances: with/without the in-kernel bounce count, with/without the small-sphere tests in the scan
+		void (*k)(float4 *, const KParams, const SceneTables, const uint64_t *, unsigned long long *) =
+			la.count ? (la.p.trioSkipMask ? pt_render_lds_kernel<true, true> : pt_render_lds_kernel<true, false>)
+			         : (la.p.trioSkipMask ? pt_render_lds_kernel<false, true> : pt_render_lds_kernel<false, false>);
+		hipLaunchKernelGGL(k, grid, block, la.ldsBytes, la.stream, la.image, la.p, la.sc, la.seedmul, la.bounceCounter);
 	} else {
 		const bool g = la.kernel == PT_K_GRID;
 		if(la.count && g) hipLaunchKernelGGL((pt_render_stream_kernel<true, true>), sgrid, dim3(64), 0, la.stream, la.image, la.p, la.sc, la.seedmul, la.bounceCounter, la.queue, la.grid);

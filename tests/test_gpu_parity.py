@@ -312,3 +312,21 @@ def test_both_kernels_on_every_small_fixture(ctx, kernel, name):
         os.environ.pop("PT_KERNEL", None)
     assert np.array_equal(bits(img[..., :3]), bits(g["strict"])), mismatch_report(img[..., :3], g["strict"])
     assert int(img[..., 3].astype(np.float64).sum()) == bc
+
+
+@pytest.mark.parametrize("name", sorted(n for n in CASES if not n.startswith(("dense", "empty"))))
+def test_small_sphere_tests_in_the_scan_change_nothing(ctx, name):
+    """The lock-step kernel's wave-level "can any lane hit it" tests (trios holding a sphere much smaller than the
+    largest one, pt_render's trioSkipMask) are a speed heuristic: with them switched off (PT_NO_TRIO_SKIP, the other
+    template instance of the kernel) the image is the same strict reference fixture."""
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    W, H, depth, spp = (int(x) for x in g["size"])
+    sc = {"spheres": g["spheres"], "bg": g["bg"], "cam": g["cam"]}
+    try:
+        os.environ["PT_NO_TRIO_SKIP"] = "1"
+        os.environ["PT_KERNEL"] = "lds"
+        img, _ = hip.render_scene(ctx, sc, W, H, depth, g["seeds"], count_bounces=True)
+    finally:
+        os.environ.pop("PT_NO_TRIO_SKIP", None)
+        os.environ.pop("PT_KERNEL", None)
+    assert np.array_equal(bits(img[..., :3]), bits(g["strict"])), mismatch_report(img[..., :3], g["strict"])
