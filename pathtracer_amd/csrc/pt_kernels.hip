@@ -386,6 +386,26 @@ static int local_rows(int H, int rank, int world, int band) {
 	return rows;
 }
 
+// Speed heuristic for the kernel choice: do rays from `pos` along the 26 axis and diagonal directions all hit a
+// sphere (near root, as src/cl/ray.cl:71-87)?  Then the scene is closed around the camera and paths run long.
+static bool camera_is_enclosed(const pt_ctx *c, const float *pos) {
+	if(!c->hostSpheres || c->nSpheres == 0) return false;
+	for(int dx = -1; dx <= 1; dx++) for(int dy = -1; dy <= 1; dy++) for(int dz = -1; dz <= 1; dz++) {
+		if(!dx && !dy && !dz) continue;
+		const double a = (double)(dx * dx + dy * dy + dz * dz);
+		bool hit = false;
+		for(int i = 0; i < c->nSpheres && !hit; i++) {
+			const float4 s = c->hostSpheres[i];
+			const double ox = pos[0] - s.x, oy = pos[1] - s.y, oz = pos[2] - s.z;
+			const double bHalf = ox * dx + oy * dy + oz * dz;
+			const double disc = bHalf * bHalf - a * (ox * ox + oy * oy + oz * oz - (double)s.w * s.w);
+			hit = disc >= 0.0 && -bHalf - sqrt(disc) > 0.0;
+		}
+		if(!hit) return false;
+	}
+	return true;
+}
+
 extern "C" int pt_render(pt_ctx *c, const pt_render_args *a) {
 	if(!c || !a) return fail(PT_E_INVALID, "pt_render: NULL%s", NULL);
 	if(a->width <= 0 || a->height <= 0 || a->max_depth < 0 || a->n_frames < 0 || a->first_frame < 0)
@@ -467,12 +487,15 @@ extern "C" int pt_render(pt_ctx *c, const pt_render_args *a) {
 	la.stream = st; la.count = a->bounce_count != NULL;
 	la.gridPixels = (unsigned)(((lp << p.logS) + 255) / 256);
 	// Up to PT_LOCKSTEP_MAX_SPHERES spheres: the lock-step kernel with the whole table in LDS and a branch-free
-	// scan (the reference's own scene has 9).  Beyond that the persistent streaming kernel wins even where the
-	// table would still fit in LDS, because its scan skips the spheres no lane can hit and its lanes never idle
-	// (1080p, 500 random spheres: 27.7 ms lock-step, 8.2 ms streaming; 40 spheres in a closed box: 114 vs 108 ms;
-	// the 9-sphere box: 60 vs 107 ms).
+	// scan (the reference's own scene has 9).  Beyond that the persistent streaming kernel wins on open scenes even
+	// where the table would still fit in LDS, because paths end after a few bounces and its lanes never idle (1080p,
+	// 500 random spheres: 40.7 ms lock-step, 7.6 ms streaming).  In a CLOSED scene paths run to the depth limit, no
+	// lane idles, and the lock-step kernel stays ahead up to about a hundred spheres (39 spheres in the box: 72 vs
+	// 97 ms; 137: 58 vs 55 ms; 355: 175 vs 117 ms): it is chosen up to PT_LOCKSTEP_MAX_CLOSED when rays from the
+	// camera in all 26 axis and diagonal directions hit something.  Either kernel gives the same image.
 	const char *force = getenv("PT_KERNEL");      // debugging aid: "stream" or "lds" overrides the choice
 	la.kernel = c->nSpheres <= PT_LOCKSTEP_MAX_SPHERES ? PT_K_LDS : PT_K_STREAM;
+	if(la.kernel == PT_K_STREAM && c->nSpheres <= PT_LOCKSTEP_MAX_CLOSED && camera_is_enclosed(c, a->cam_pos)) la.kernel = PT_K_LDS;
 	if(force && strcmp(force, "stream") == 0 && c->nSpheres > 0) la.kernel = PT_K_STREAM;
 	if(force && strcmp(force, "lds") == 0 && c->nSpheres <= PT_LDS_MAX_SPHERES) la.kernel = PT_K_LDS;
 	// opt-in acceleration structure (no reference counterpart): same closest hit, found through a uniform grid

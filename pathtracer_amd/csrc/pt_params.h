@@ -9,8 +9,9 @@
 // Kernel parameters (by value: land in SGPRs — the reference passes its three structs by
 // value too, src/c/renderer.c:160-162)
 // ---------------------------------------------------------------------------------------
-#define PT_LDS_MAX_SPHERES 512       // what the lock-step kernel can hold: 24 KB of LDS per 256-thread block (PT_KERNEL=lds)
-#define PT_LOCKSTEP_MAX_SPHERES 16   // what it is chosen for (pt_render)
+#define PT_LDS_MAX_SPHERES 512       // what the lock-step kernel can hold: 27 KB of LDS per 256-thread block (PT_KERNEL=lds)
+#define PT_LOCKSTEP_MAX_SPHERES 16   // what it is chosen for (pt_render) ...
+#define PT_LOCKSTEP_MAX_CLOSED 64    // ... and up to here when the camera sits in a closed scene (long paths, no idle lanes)
 
 struct KParams {
 	int W, H, maxDepth, n;

@@ -114,16 +114,20 @@ def dense_random(n=10000, seed=12345):
     return _pack(s, [0.5, 0.7, 1.0], cam)
 
 
-def glass_lattice():
+def glass_lattice(k=3):
     """Config 5 — divergence stress: the frame-0 box with the glass sphere replaced by a
-    3x3x3 lattice of dielectric spheres and four small emissive spheres (depth 32)."""
+    3x3x3 lattice of dielectric spheres and four small emissive spheres (depth 32).
+    k > 3: the same 1.8-unit cube filled with k^3 proportionally smaller spheres (closed scenes with larger tables)."""
     base = main_lua_frame(0)
-    keep = [row for k, row in enumerate(base["spheres"].tolist()) if k != 6]
+    keep = [row for j, row in enumerate(base["spheres"].tolist()) if j != 6]
     glass = dielectric(1, 1, 1, 0.2, 0, 1.5)
-    for ix in (-1, 0, 1):
-        for iy in (-1, 0, 1):
-            for iz in (-1, 0, 1):
-                keep.append(_sphere(-1 + 0.9 * ix, 0.9 * iy, -10 + 0.9 * iz, 0.4, glass))
+    step = 0.9 if k == 3 else 1.8 / (k - 1)
+    rad = 0.4 if k == 3 else step * 0.4 / 0.9
+    half = (k - 1) / 2.0
+    for ix in range(k):
+        for iy in range(k):
+            for iz in range(k):
+                keep.append(_sphere(-1 + step * (ix - half), step * (iy - half), -10 + step * (iz - half), rad, glass))
     for (x, y, z) in ((-3.5, 2.5, -11), (2.0, -2.5, -9), (-2.5, -2.0, -13), (1.5, 3.0, -12)):
         keep.append(_sphere(x, y, z, 0.3, light_source(10, 8, 6)))
     return {"spheres": np.asarray(keep, dtype=np.float32), "bg": base["bg"], "cam": base["cam"]}
