@@ -464,13 +464,14 @@ extern "C" int pt_render(pt_ctx *c, const pt_render_args *a) {
 
 	SceneTables sc = {c->geom, c->matA, c->matB};
 	// LDS kernel: enough lanes per pixel that the launch has about a dozen rounds of the chip's 8192 wave
-	// slots (measured on the 1080p headline frame: 243 ms at 1 lane per pixel, 231 ms at 4; 640x360: 289 -> 218 ms at 8)
+	// slots, at most 16 (measured: the 1080p headline frame 243 ms at 1 lane per pixel, 231 ms at 4; one rank's eighth
+	// of it 32.9 / 28.6 / 26.1 / 25.0 / 24.4 ms at 1 / 2 / 4 / 8 / 16 lanes, 25.1 ms at 32)
 	p.logS = 0;
 	{
 		const char *fs = getenv("PT_LANES_PER_PIXEL");      // debugging aid: force 1, 2, 4 or 8
 		int want = 0;
 		if(fs) { int v = atoi(fs); while((1 << want) < v && want < 5) want++; }
-		else while(want < 3 && (lp << want) < 64ll * 12 * 8192 && (2 << want) <= a->n_frames) want++;
+		else while(want < 4 && (lp << want) < 64ll * 12 * 8192 && (2 << want) <= a->n_frames) want++;
 		p.logS = want;
 	}
 	// LDS kernel: trios of the table that hold a sphere much smaller than the largest one get a wave-level "can any

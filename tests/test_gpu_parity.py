@@ -157,21 +157,21 @@ def test_sample_interleaved_lanes_are_bit_identical(ctx, oracle):
     the bits of 1 lane per pixel: odd sample counts, fewer samples than lanes, continued accumulators."""
     g = np.load(os.path.join(GOLD, "lattice_96x54.npz"))
     sc = {"spheres": g["spheres"], "bg": g["bg"], "cam": g["cam"]}
-    stream = seedmod.glibc_rand_stream(13)
+    stream = seedmod.glibc_rand_stream(40)
     try:
         os.environ["PT_LANES_PER_PIXEL"] = "1"
-        ref = {n: hip.render_scene(ctx, sc, 96, 54, 32, stream[:n], count_bounces=True) for n in (1, 3, 8, 13)}
+        ref = {n: hip.render_scene(ctx, sc, 96, 54, 32, stream[:n], count_bounces=True) for n in (1, 3, 8, 13, 40)}
         want = oracle.render(sc, 96, 54, 32, stream[:13])
         assert np.array_equal(bits(ref[13][0][..., :3]), bits(want[..., :3]))
-        for lanes in (2, 4, 8):
+        for lanes in (2, 4, 8, 16, 32):
             os.environ["PT_LANES_PER_PIXEL"] = str(lanes)
-            for n in (1, 3, 8, 13):
+            for n in (1, 3, 8, 13, 40):
                 img, bc = hip.render_scene(ctx, sc, 96, 54, 32, stream[:n], count_bounces=True)
                 assert np.array_equal(bits(img), bits(ref[n][0])), (lanes, n)      # incl. the per-pixel counts
                 assert bc == ref[n][1]
             ctx.image_alloc(96, 54)
             ctx.render(sc, 96, 54, 32, stream[:5])
-            ctx.render(sc, 96, 54, 32, stream[5:], first_frame=5)
+            ctx.render(sc, 96, 54, 32, stream[5:13], first_frame=5)
             assert np.array_equal(bits(ctx.image_read()[..., :3]), bits(ref[13][0][..., :3])), lanes
     finally:
         os.environ.pop("PT_LANES_PER_PIXEL", None)
