@@ -134,7 +134,9 @@ int pt_image_read_u8(pt_ctx *ctx, const void *d_image, int width, int height, un
  *   op 4: float bit patterns a[i] .. a[i]+b[i]-1: out_u64[i] = (#patterns where the kernels' short
  *         correctly-rounded sqrt differs from sqrtf inside its stated domain) << 32
  *         | #patterns where their guarded sqrt differs from sqrtf anywhere
- *   op 5: same ranges: out_u64[i] = #patterns where the kernels' short reciprocal differs from 1.0f / x */
+ *   op 5: same ranges: out_u64[i] = #patterns where the kernels' short reciprocal differs from 1.0f / x
+ *   op 6: b[i] pseudo-random (num, den) pairs from seed a[i], 2^-80 <= num < 2^80, 2^-40 <= den < 2^40:
+ *         out_u64[i] = #pairs where the scan's short divide differs from num / den */
 int pt_selftest(pt_ctx *ctx, int op, const uint64_t *a, const uint64_t *b, const float *in_f,
                 int n, uint64_t *out_u64, float *out_f);
 

@@ -219,6 +219,15 @@ PT_DEV void scan_chunk(const float4 *buf, int count4, int base, f3 o, f3 d, floa
 	}
 }
 
+// Start value of the scan's small-|disc| tracker: folds the lower bound on `a` into the same compare (finish_scan).
+PT_DEV float scan_tiny_init(float a) {
+#if PT_FAST_MATH
+	return 0.0f;
+#else
+	return a * 0x1p-56f;
+#endif
+}
+
 // End of a scan: the single divide, and the checks that send a lane to the reference scan (`slow`).
 PT_DEV Hit finish_scan(float a, uint32_t best, uint32_t prev, int idx, float tiny, bool &slow) {
 	Hit h;
@@ -232,9 +241,11 @@ PT_DEV Hit finish_scan(float a, uint32_t best, uint32_t prev, int idx, float tin
 #endif
 	const float num = __uint_as_float(best);
 	const float pnum = __uint_as_float(prev);                // +inf when there is none
-	h.t = num / a;
-	slow = tiny < 0x1p-96f;      // some |disc| below sqrt_nt's domain (an exactly zero disc lands here too: rare, and exact either way)
-	slow |= !(a >= 0x1p-40f && a <= 0x1p40f);
+	h.t = div_nt(num, a);        // exact inside the ranges checked below; outside them the lane is `slow` or has no hit
+	// `tiny` starts at a * 2^-56 (scan_tiny_init) and then takes the smallest |disc|: below 2^-96 means a < 2^-40, or
+	// some |disc| under sqrt_nt's domain (an exactly zero disc lands here too: rare, and exact either way)
+	slow = tiny < 0x1p-96f;
+	slow |= !(a <= 0x1p40f);
 	slow |= h.hit && (!(num >= 0x1p-80f && num <= 0x1p80f) || pnum <= num * (1.0f + 0x1p-21f));
 	return h;
 }
@@ -323,7 +334,7 @@ PT_DEV bool wave_can_hit(float disc, float bHalf) {
 template <bool SKIP>
 PT_DEV Hit closest_hit_lds(uint32_t base, int n, unsigned skipMask, f3 o, f3 d, float a) {
 	uint32_t best = KEY_NONE, prev = KEY_NONE;
-	float tiny = __builtin_inff();
+	float tiny = scan_tiny_init(a);
 	int idx = 0;
 	uint32_t addr = base;
 	int i = 0;
@@ -627,7 +638,7 @@ __global__ __launch_bounds__(64) void pt_render_stream_kernel(float4 *__restrict
 		} else if(__popcll(tmask) > PT_COOP_MAX_LANES) {
 			// ray-parallel: every lane scans the whole table for its own ray
 			uint32_t best = KEY_NONE, prev = KEY_NONE;
-			float tiny = __builtin_inff();
+			float tiny = scan_tiny_init(a);
 			int idx = 0;
 			if(nchunks > 1) {      // a table of one chunk was staged once, before the loop
 				sChunk[0][lane] = lane < p.n ? sc.geom[lane] : PT_PAD_SPHERE;

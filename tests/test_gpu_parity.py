@@ -91,6 +91,15 @@ def test_short_reciprocal_is_the_divide_on_every_float(ctx):
     assert len(bad) == 0, "rcp_cr != 1/x in %d chunks, first at bits 0x%08x" % (len(bad), int(bad[0]) << 16)
 
 
+def test_short_divide_is_the_divide_on_its_range(ctx):
+    """finish_scan's divide (pt_device.h div_nt: the compiler's expansion without range scaling and special-case
+    fix-up) against the compiler's correctly rounded divide on 2^32 pseudo-random operand pairs of the range the scan
+    guarantees, plus the corners of that range, on the device."""
+    n = 1 << 16
+    ou, _ = ctx.selftest(6, a=np.arange(n, dtype=np.uint64), b=np.full(n, 1 << 16, np.uint64))
+    assert int(ou.sum()) == 0, "div_nt != / somewhere"
+
+
 def test_kernel_timing_ring(ctx):
     sc = scenes.main_lua_frame(0)
     ctx.scene_upload(sc["spheres"])
