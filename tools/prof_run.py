@@ -1,6 +1,6 @@
 """Profiling driver: one 1080p render of a named scene through the C ABI, no torch (rocprofv3 target).
 
-    python3 tools/prof_run.py [scene=frame0] [spp=32] [reps=1] [depth=50] [W=1920] [H=1080]
+    python3 tools/prof_run.py [scene=frame0] [spp=32] [reps=1] [depth=50] [W=1920] [H=1080] [world=1] [rank=0] [band_rows=8]
 """
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -27,7 +27,9 @@ def main():
     depth = int(a[3]) if len(a) > 3 else 50
     W = int(a[4]) if len(a) > 4 else 1920
     H = int(a[5]) if len(a) > 5 else 1080
-    world = int(a[6]) if len(a) > 6 else 1       # render only rank 0's bands of a `world`-way split
+    world = int(a[6]) if len(a) > 6 else 1       # render only one rank's bands of a `world`-way split ...
+    rank = int(a[7]) if len(a) > 7 else 0         # ... this rank's
+    band = int(a[8]) if len(a) > 8 else 8
     fast = os.environ.get("PT_MATH") == "fast"
     sc = SCENES[name]()
     s = seedmod.glibc_rand_stream(spp)
@@ -40,7 +42,7 @@ def main():
         print("bounce iterations per sample: %.3f (over %d spp)" % (bc / (W * H * len(cs)), len(cs)), flush=True)
     for r in range(reps):
         t0 = time.perf_counter()
-        ms = ctx.render(sc, W, H, depth, s, time_kernel=True, world=world, band_rows=8)
+        ms = ctx.render(sc, W, H, depth, s, time_kernel=True, rank=rank, world=world, band_rows=band)
         dt = time.perf_counter() - t0
         print("%s %dx%d spp %d depth %d: kernel %.3f ms (wall %.3f ms) -> %.1f Msamples/s" %
               (name, W, H, spp, depth, ms, dt * 1e3, W * H * spp / world / ms / 1e3), flush=True)
