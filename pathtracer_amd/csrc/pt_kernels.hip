@@ -472,6 +472,7 @@ extern "C" int pt_render(pt_ctx *c, const pt_render_args *a) {
 		int want = 0;
 		if(fs) { int v = atoi(fs); while((1 << want) < v && want < 5) want++; }
 		else while(want < 4 && (lp << want) < 64ll * 12 * 8192 && (2 << want) <= a->n_frames) want++;
+		if((long long)a->first_frame + a->n_frames >= (1 << 24)) want = 0;      // the group accumulation counts frames in float
 		p.logS = want;
 	}
 	// LDS kernel: trios of the table that hold a sphere much smaller than the largest one get a wave-level "can any

@@ -52,11 +52,14 @@ PT_DEV void start_sample(Path &pt, const KParams &p, int id, f3 origin, uint64_t
 	pt.mask = mk3(1.0f, 1.0f, 1.0f);                                                     // ray.cl:93
 }
 
-// src/cl/main.cl:27-29 — exposure scale and the running mean with frame = f
+// src/cl/main.cl:27-29 — exposure scale, then the running mean with frame = f (two steps, so that lanes sharing a
+// pixel scale their own sample once and repeat only the mean)
+PT_DEV f3 expose(f3 color, const KParams &p) { return scl3(scl3(color, p.exposure), p.aperture); }       // main.cl:27
+PT_DEV f3 running_mean(f3 acc, f3 color, float f, float f1) {                                             // main.cl:29
+	return mk3(pt_div(acc.x * f + color.x, f1), pt_div(acc.y * f + color.y, f1), pt_div(acc.z * f + color.z, f1));
+}
 PT_DEV f3 accumulate(f3 acc, f3 color, const KParams &p, int frame) {
-	color = scl3(scl3(color, p.exposure), p.aperture);                                   // main.cl:27
-	const float f = (float)frame, f1 = (float)(frame + 1);
-	return mk3(pt_div(acc.x * f + color.x, f1), pt_div(acc.y * f + color.y, f1), pt_div(acc.z * f + color.z, f1));   // main.cl:29
+	return running_mean(acc, expose(color, p), (float)frame, (float)(frame + 1));
 }
 
 // src/cl/ray.cl:117-171 — everything after the closest hit is known.  Returns true when the path
@@ -433,9 +436,11 @@ __global__ __launch_bounds__(256) void pt_render_lds_kernel(float4 *__restrict__
 			if(S == 1) acc = accumulate(acc, color, p, p.firstFrame + k0);
 			else {
 				const int round = p.nFrames - k0 < S ? p.nFrames - k0 : S;
-				for(int s = 0; s < round; s++) {
+				color = expose(color, p);
+				float f = (float)(p.firstFrame + k0);      // frame numbers stay below 2^24 when S > 1 (pt_render): f + 1.0f is exact
+				for(int s = 0; s < round; s++, f += 1.0f) {
 					const f3 c = mk3(__shfl(color.x, groupBase + s, 64), __shfl(color.y, groupBase + s, 64), __shfl(color.z, groupBase + s, 64));
-					acc = accumulate(acc, c, p, p.firstFrame + k0 + s);
+					acc = running_mean(acc, c, f, f + 1.0f);
 				}
 			}
 		}
