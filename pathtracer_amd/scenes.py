@@ -133,6 +133,21 @@ def glass_lattice(k=3):
     return {"spheres": np.asarray(keep, dtype=np.float32), "bg": base["bg"], "cam": base["cam"]}
 
 
+def scaled(scene, log2_scale):
+    """The same scene in other units: every length times 2^log2_scale (exact), exposure divided by it.  At
+    2^-45 .. 2^-60 the discriminants and hit parameters leave the ranges the kernels' short arithmetic is exact on
+    (everything goes to the reference scan); at 2^50 they approach overflow, at 2^57 they overflow to inf/NaN.
+    The reference's fixed 0.0001 offset (src/cl/ray.cl:119) is not scaled, so these are different images."""
+    k = np.float32(2.0) ** np.float32(log2_scale)
+    sp = scene["spheres"].copy()
+    sp[:, :4] *= k
+    cam = scene["cam"].copy()
+    cam[0:3] *= k
+    cam[6:9] *= k          # sensorWidth, focalLength, aperture
+    cam[9] /= k            # exposure: colour = colour * exposure * aperture (src/cl/main.cl:27)
+    return {"spheres": sp, "bg": scene["bg"].copy(), "cam": cam}
+
+
 def material_micro(kind):
     """One sphere of one material under a bright sky — one scene per shading branch."""
     mats = {

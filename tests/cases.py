@@ -23,5 +23,13 @@ CASES = {
     "dielectric_low_64x48": (lambda: scenes.material_micro("dielectric_low"), 64, 48, 50, 8),
     "depth0_16x16": (lambda: scenes.main_lua_frame(0), 16, 16, 0, 2),       # maxDepth 0: loop never runs -> black
     "depth1_32x32": (lambda: scenes.main_lua_frame(3), 32, 32, 1, 4),
+    # other units: hit parameters and discriminants outside the ranges of the kernels' short arithmetic (range guards,
+    # reference-scan fallback), near overflow, and past it (inf / NaN everywhere)
+    "frame0_scale_m45_48x27": (lambda: scenes.scaled(scenes.main_lua_frame(0), -45), 48, 27, 50, 4),
+    "frame0_scale_m60_48x27": (lambda: scenes.scaled(scenes.main_lua_frame(0), -60), 48, 27, 50, 4),
+    "frame0_scale_p50_48x27": (lambda: scenes.scaled(scenes.main_lua_frame(0), 50), 48, 27, 50, 4),
+    "frame0_scale_p57_48x27": (lambda: scenes.scaled(scenes.main_lua_frame(0), 57), 48, 27, 50, 4),
+    "micro_scale_m40_48x36": (lambda: scenes.scaled(scenes.material_micro("dielectric"), -40), 48, 36, 50, 4),
+    "micro_scale_p40_48x36": (lambda: scenes.scaled(scenes.material_micro("metal"), 40), 48, 36, 50, 4),
     "one_pixel": (lambda: scenes.main_lua_frame(0), 1, 1, 50, 4),           # id 0: RNG stuck at 0
 }
