@@ -156,6 +156,10 @@ def material_micro(kind):
         "metal": metal(0.9, 0.7, 0.5, 0.6, 0.25),
         "dielectric": dielectric(0.6, 0.9, 0.7, 0.5, 0.1, 1.5),
         "dielectric_low": dielectric(0.2, 1.0, 0.3, 0.8, 0.0, 0.95),
+        # directions of length ~2^25 and ~2^70 after the first bounce: a = |d|^2 outside the scan's [2^-40, 2^40], and overflowing
+        "metal_fuzz25": metal(0.9, 0.7, 0.5, 0.6, 2.0 ** 25),
+        "metal_fuzz70": metal(0.9, 0.7, 0.5, 0.6, 2.0 ** 70),
+        "dielectric_idx30": dielectric(0.6, 0.9, 0.7, 0.5, 0.1, 2.0 ** 30),
     }
     s = [
         _sphere(0, 0, -6, 1.5, mats[kind]),

@@ -31,5 +31,9 @@ CASES = {
     "frame0_scale_p57_48x27": (lambda: scenes.scaled(scenes.main_lua_frame(0), 57), 48, 27, 50, 4),
     "micro_scale_m40_48x36": (lambda: scenes.scaled(scenes.material_micro("dielectric"), -40), 48, 36, 50, 4),
     "micro_scale_p40_48x36": (lambda: scenes.scaled(scenes.material_micro("metal"), 40), 48, 36, 50, 4),
+    # directions far from unit length (a = |d|^2 outside the scan's range, and overflowing), an absurd refraction index
+    "metal_fuzz25_48x36": (lambda: scenes.material_micro("metal_fuzz25"), 48, 36, 50, 4),
+    "metal_fuzz70_48x36": (lambda: scenes.material_micro("metal_fuzz70"), 48, 36, 50, 4),
+    "dielectric_idx30_48x36": (lambda: scenes.material_micro("dielectric_idx30"), 48, 36, 50, 4),
     "one_pixel": (lambda: scenes.main_lua_frame(0), 1, 1, 50, 4),           # id 0: RNG stuck at 0
 }
