@@ -136,6 +136,28 @@ MIXKERNEL(x_pk2_cmp2, "v_pk_mul_f32 %0, %0, %4\n v_cmp_lt_f32 vcc, %2, %6\n v_pk
 MIXKERNEL(x_pkfma2_add2, "v_pk_fma_f32 %0, %0, %4, %5\n v_add_f32 %2, %2, %6\n v_pk_fma_f32 %1, %1, %5, %4\n v_add_f32 %3, %3, %7\n")
 MIXKERNEL(x_sqrt_pk3, "v_sqrt_f32 %2, %2\n v_pk_mul_f32 %0, %0, %4\n v_pk_add_f32 %1, %1, %5\n v_pk_mul_f32 %0, %0, %5\n")
 
+
+// LDS read throughput: wave-uniform (broadcast) and per-lane ds_read_b128 / b64 / b32, 64 reads per loop trip
+#define LDSKERNEL(name, INS, ADDR)                                                  \
+	__global__ __launch_bounds__(256) void name(float *out, int reps) {             \
+		__shared__ float4 buf[1024];                                                \
+		for(int i = threadIdx.x; i < 1024; i += 256) buf[i] = make_float4(i, 1, 2, 3); \
+		__syncthreads();                                                            \
+		unsigned addr = (unsigned)(size_t)buf + (ADDR);                             \
+		float acc = 0;                                                              \
+		for(int r = 0; r < reps; r++) {                                             \
+			float4 v0, v1, v2, v3;                                                  \
+			for(int k = 0; k < 16; k++) {                                           \
+				asm volatile(INS " %0, %4\n" INS " %1, %4 offset:16\n" INS " %2, %4 offset:32\n" INS " %3, %4 offset:48\n s_waitcnt lgkmcnt(0)\n" \
+				             : "=v"(v0), "=v"(v1), "=v"(v2), "=v"(v3) : "v"(addr));  \
+				acc += v0.x + v1.x + v2.x + v3.x;                                   \
+			}                                                                       \
+		}                                                                           \
+		out[blockIdx.x * blockDim.x + threadIdx.x] = acc;                           \
+	}
+LDSKERNEL(l_b128_uniform, "ds_read_b128", 0)
+LDSKERNEL(l_b128_perlane, "ds_read_b128", (threadIdx.x & 63) * 64)
+
 typedef void (*kfn)(float *, int);
 struct Entry { const char *name; kfn fn; };
 #define E(n) {#n, n}
@@ -143,7 +165,7 @@ struct Entry { const char *name; kfn fn; };
 int main(int argc, char **argv) {
 	Entry es[] = {E(k_mul_f32), E(k_fma_f32), E(k_sqrt_f32), E(k_rcp_f32), E(k_cndmask), E(k_cmp_f32), E(k_cmp_sgpr), E(k_min_f32),
 	              E(k_add_u32), E(k_mul_lo_u32), E(k_mul_hi_u32), E(k_cvt_f32_u32), E(k_mul_f64), E(k_fma_f64), E(k_mad_u64_u32),
-	              E(k_cvt_f64_u32), E(k_cvt_f32_f64), E(k_pk_mul_f32), E(k_pk_add_f32), E(k_pk_fma_f32), E(k_readlane), E(k_salu), E(k_cndmask_nodep), E(k_cndmask_sgpr), E(k_cmp_cnd_pair), E(k_add_f32), E(k_max_f32), E(k_and_b32), E(k_mov_b32), E(k_lshl_add), E(k_min_u32), E(k_min3_f32), E(k_med3_f32), E(k_mul_legacy), E(k_rsq_f32), E(k_div_scale), E(k_div_fmas), E(k_div_fixup), E(k_cmp_class), E(k_mul_sgpr), E(k_fma_sgpr), E(k_sub_sgpr), E(x_pk2_add2), E(x_pk1_add3), E(x_pk3_add1), E(x_pk2_cmp2), E(x_pkfma2_add2), E(x_sqrt_pk3), E(m_cmp_add3), E(m_cmp2_add2), E(m_cmp3_add1), E(m_sqrt_add3), E(m_sqrt_cmp_add2), E(m_sqrt_cmp3), E(m_min_cnd_mul_fma), E(m_fma3_cmp), E(m_min_add3), E(m_cnd_add3), E(m_add_mul), E(k_ashr_i32), E(k_lshr_b32), E(k_lshl_b32), E(k_sub_u32), E(k_xor_b32), E(k_or_b32), E(k_bfe_u32), E(k_add3_u32), E(k_and_or_b32), E(k_fmac_f32), E(k_add_f32_neg), E(k_sub_f32), E(k_add_f32_abs), E(k_addc_co), E(k_subb_co), E(k_add_co), E(k_max_u32), E(k_med3_u32), E(k_min_i32), E(k_bfi_b32), E(k_perm_b32), E(k_mul_u32_u24), E(k_mad_u32_u24), E(k_xad_u32), E(k_cmp_lt_u32), E(k_sqrt_add_mix), E(k_cmp_add_mix), E(k_ldexp_f32), E(k_frexp_mant)};
+	              E(k_cvt_f64_u32), E(k_cvt_f32_f64), E(k_pk_mul_f32), E(k_pk_add_f32), E(k_pk_fma_f32), E(k_readlane), E(k_salu), E(k_cndmask_nodep), E(k_cndmask_sgpr), E(k_cmp_cnd_pair), E(k_add_f32), E(k_max_f32), E(k_and_b32), E(k_mov_b32), E(k_lshl_add), E(k_min_u32), E(k_min3_f32), E(k_med3_f32), E(k_mul_legacy), E(k_rsq_f32), E(k_div_scale), E(k_div_fmas), E(k_div_fixup), E(k_cmp_class), E(k_mul_sgpr), E(k_fma_sgpr), E(k_sub_sgpr), E(l_b128_uniform), E(l_b128_perlane), E(x_pk2_add2), E(x_pk1_add3), E(x_pk3_add1), E(x_pk2_cmp2), E(x_pkfma2_add2), E(x_sqrt_pk3), E(m_cmp_add3), E(m_cmp2_add2), E(m_cmp3_add1), E(m_sqrt_add3), E(m_sqrt_cmp_add2), E(m_sqrt_cmp3), E(m_min_cnd_mul_fma), E(m_fma3_cmp), E(m_min_add3), E(m_cnd_add3), E(m_add_mul), E(k_ashr_i32), E(k_lshr_b32), E(k_lshl_b32), E(k_sub_u32), E(k_xor_b32), E(k_or_b32), E(k_bfe_u32), E(k_add3_u32), E(k_and_or_b32), E(k_fmac_f32), E(k_add_f32_neg), E(k_sub_f32), E(k_add_f32_abs), E(k_addc_co), E(k_subb_co), E(k_add_co), E(k_max_u32), E(k_med3_u32), E(k_min_i32), E(k_bfi_b32), E(k_perm_b32), E(k_mul_u32_u24), E(k_mad_u32_u24), E(k_xad_u32), E(k_cmp_lt_u32), E(k_sqrt_add_mix), E(k_cmp_add_mix), E(k_ldexp_f32), E(k_frexp_mant)};
 	int wavesPerSimd = argc > 1 ? atoi(argv[1]) : 8;
 	int blocks = 256 * wavesPerSimd;   // 256 CUs x (wavesPerSimd*4 waves / 4 waves per block)
 	float *out;
