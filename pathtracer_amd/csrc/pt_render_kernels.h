@@ -320,9 +320,6 @@ struct LdsGeom {      // geom[i] for closest_hit_reference
 	PT_DEV float4 operator[](int i) const { return lds_f4(base + lds_record_offset(i)); }
 };
 
-// Returns Hit.idx = LDS address of the winner's record.  `a` may be wrong when dot(d, d) < 2^-96 (the caller uses
-// the unguarded sqrt_nt); it is then below 2^-40, finish_scan() asks for the reference scan, and that gets the
-// exact value.
 // Wave-level "can any lane hit this sphere": a hit needs disc >= 0 and bHalf < 0 (then -bHalf > sqrt(disc) is
 // possible); min(disc, -bHalf) >= 0 is a superset of that, and what it rules out is no hit in the reference either
 // (disc < 0: ray.cl:78; bHalf >= 0: t <= 0, ray.cl:82).  One v_min with a source modifier, one compare, one scalar branch.
@@ -332,6 +329,9 @@ PT_DEV bool wave_can_hit(float disc, float bHalf) {
 	return __builtin_amdgcn_ballot_w64(m >= 0.0f) != 0;
 }
 
+// Returns Hit.idx = LDS address of the winner's record.  `a` may be wrong when dot(d, d) < 2^-96 (the caller uses
+// the unguarded sqrt_nt); it is then below 2^-40, scan_tiny_init() starts the small-|disc| tracker below 2^-96,
+// finish_scan() asks for the reference scan, and that gets the exact value.
 // `skipMask` bit t: trio t holds a sphere much smaller than the largest of the table (set by the host); such a sphere
 // is rarely a candidate for any of the 64 rays of a wave, and its sqrt/select part is entered only if it is.
 template <bool SKIP>
