@@ -158,6 +158,12 @@ MIXKERNEL(x_sqrt_pk3, "v_sqrt_f32 %2, %2\n v_pk_mul_f32 %0, %0, %4\n v_pk_add_f3
 LDSKERNEL(l_b128_uniform, "ds_read_b128", 0)
 LDSKERNEL(l_b128_perlane, "ds_read_b128", (threadIdx.x & 63) * 64)
 
+KERNEL(t_sqrt_add7, F32DECL, "v_sqrt_f32 %0, %0\n v_add_f32 %1, %1, %4\n v_add_f32 %2, %2, %5\n v_add_f32 %3, %3, %4\n v_add_f32 %1, %1, %5\n v_add_f32 %2, %2, %4\n v_add_f32 %3, %3, %5\n v_add_f32 %1, %1, %4\n ")
+KERNEL(t_sqrt_add15, F32DECL, "v_sqrt_f32 %0, %0\n v_add_f32 %1, %1, %4\n v_add_f32 %2, %2, %5\n v_add_f32 %3, %3, %4\n v_add_f32 %1, %1, %5\n v_add_f32 %2, %2, %4\n v_add_f32 %3, %3, %5\n v_add_f32 %1, %1, %4\n v_add_f32 %2, %2, %5\n v_add_f32 %3, %3, %4\n v_add_f32 %1, %1, %5\n v_add_f32 %2, %2, %4\n v_add_f32 %3, %3, %5\n v_add_f32 %1, %1, %4\n v_add_f32 %2, %2, %5\n v_add_f32 %3, %3, %4\n ")
+KERNEL(t_sqrt_add31, F32DECL, "v_sqrt_f32 %0, %0\n v_add_f32 %1, %1, %4\n v_add_f32 %2, %2, %5\n v_add_f32 %3, %3, %4\n v_add_f32 %1, %1, %5\n v_add_f32 %2, %2, %4\n v_add_f32 %3, %3, %5\n v_add_f32 %1, %1, %4\n v_add_f32 %2, %2, %5\n v_add_f32 %3, %3, %4\n v_add_f32 %1, %1, %5\n v_add_f32 %2, %2, %4\n v_add_f32 %3, %3, %5\n v_add_f32 %1, %1, %4\n v_add_f32 %2, %2, %5\n v_add_f32 %3, %3, %4\n v_add_f32 %1, %1, %5\n v_add_f32 %2, %2, %4\n v_add_f32 %3, %3, %5\n v_add_f32 %1, %1, %4\n v_add_f32 %2, %2, %5\n v_add_f32 %3, %3, %4\n v_add_f32 %1, %1, %5\n v_add_f32 %2, %2, %4\n v_add_f32 %3, %3, %5\n v_add_f32 %1, %1, %4\n v_add_f32 %2, %2, %5\n v_add_f32 %3, %3, %4\n v_add_f32 %1, %1, %5\n v_add_f32 %2, %2, %4\n v_add_f32 %3, %3, %5\n v_add_f32 %1, %1, %4\n ")
+KERNEL(t_sqrt3_add13, F32DECL, "v_sqrt_f32 %0, %0\n v_sqrt_f32 %1, %1\n v_sqrt_f32 %2, %2\n v_add_f32 %3, %3, %4\n v_add_f32 %3, %3, %5\n v_add_f32 %3, %3, %4\n v_add_f32 %3, %3, %5\n v_add_f32 %3, %3, %4\n v_add_f32 %3, %3, %5\n v_add_f32 %3, %3, %4\n v_add_f32 %3, %3, %5\n v_add_f32 %3, %3, %4\n v_add_f32 %3, %3, %5\n v_add_f32 %3, %3, %4\n v_add_f32 %3, %3, %5\n v_add_f32 %3, %3, %4\n ")
+KERNEL(t_sqrt2_add30, F32DECL, "v_sqrt_f32 %0, %0\n v_sqrt_f32 %1, %1\n v_add_f32 %2, %2, %4\n v_add_f32 %3, %3, %5\n v_add_f32 %2, %2, %4\n v_add_f32 %3, %3, %5\n v_add_f32 %2, %2, %4\n v_add_f32 %3, %3, %5\n v_add_f32 %2, %2, %4\n v_add_f32 %3, %3, %5\n v_add_f32 %2, %2, %4\n v_add_f32 %3, %3, %5\n v_add_f32 %2, %2, %4\n v_add_f32 %3, %3, %5\n v_add_f32 %2, %2, %4\n v_add_f32 %3, %3, %5\n v_add_f32 %2, %2, %4\n v_add_f32 %3, %3, %5\n v_add_f32 %2, %2, %4\n v_add_f32 %3, %3, %5\n v_add_f32 %2, %2, %4\n v_add_f32 %3, %3, %5\n v_add_f32 %2, %2, %4\n v_add_f32 %3, %3, %5\n v_add_f32 %2, %2, %4\n v_add_f32 %3, %3, %5\n v_add_f32 %2, %2, %4\n v_add_f32 %3, %3, %5\n v_add_f32 %2, %2, %4\n v_add_f32 %3, %3, %5\n v_add_f32 %2, %2, %4\n v_add_f32 %3, %3, %5\n ")
+
 typedef void (*kfn)(float *, int);
 struct Entry { const char *name; kfn fn; };
 #define E(n) {#n, n}
@@ -165,7 +171,7 @@ struct Entry { const char *name; kfn fn; };
 int main(int argc, char **argv) {
 	Entry es[] = {E(k_mul_f32), E(k_fma_f32), E(k_sqrt_f32), E(k_rcp_f32), E(k_cndmask), E(k_cmp_f32), E(k_cmp_sgpr), E(k_min_f32),
 	              E(k_add_u32), E(k_mul_lo_u32), E(k_mul_hi_u32), E(k_cvt_f32_u32), E(k_mul_f64), E(k_fma_f64), E(k_mad_u64_u32),
-	              E(k_cvt_f64_u32), E(k_cvt_f32_f64), E(k_pk_mul_f32), E(k_pk_add_f32), E(k_pk_fma_f32), E(k_readlane), E(k_salu), E(k_cndmask_nodep), E(k_cndmask_sgpr), E(k_cmp_cnd_pair), E(k_add_f32), E(k_max_f32), E(k_and_b32), E(k_mov_b32), E(k_lshl_add), E(k_min_u32), E(k_min3_f32), E(k_med3_f32), E(k_mul_legacy), E(k_rsq_f32), E(k_div_scale), E(k_div_fmas), E(k_div_fixup), E(k_cmp_class), E(k_mul_sgpr), E(k_fma_sgpr), E(k_sub_sgpr), E(l_b128_uniform), E(l_b128_perlane), E(x_pk2_add2), E(x_pk1_add3), E(x_pk3_add1), E(x_pk2_cmp2), E(x_pkfma2_add2), E(x_sqrt_pk3), E(m_cmp_add3), E(m_cmp2_add2), E(m_cmp3_add1), E(m_sqrt_add3), E(m_sqrt_cmp_add2), E(m_sqrt_cmp3), E(m_min_cnd_mul_fma), E(m_fma3_cmp), E(m_min_add3), E(m_cnd_add3), E(m_add_mul), E(k_ashr_i32), E(k_lshr_b32), E(k_lshl_b32), E(k_sub_u32), E(k_xor_b32), E(k_or_b32), E(k_bfe_u32), E(k_add3_u32), E(k_and_or_b32), E(k_fmac_f32), E(k_add_f32_neg), E(k_sub_f32), E(k_add_f32_abs), E(k_addc_co), E(k_subb_co), E(k_add_co), E(k_max_u32), E(k_med3_u32), E(k_min_i32), E(k_bfi_b32), E(k_perm_b32), E(k_mul_u32_u24), E(k_mad_u32_u24), E(k_xad_u32), E(k_cmp_lt_u32), E(k_sqrt_add_mix), E(k_cmp_add_mix), E(k_ldexp_f32), E(k_frexp_mant)};
+	              E(k_cvt_f64_u32), E(k_cvt_f32_f64), E(k_pk_mul_f32), E(k_pk_add_f32), E(k_pk_fma_f32), E(k_readlane), E(k_salu), E(k_cndmask_nodep), E(k_cndmask_sgpr), E(k_cmp_cnd_pair), E(k_add_f32), E(k_max_f32), E(k_and_b32), E(k_mov_b32), E(k_lshl_add), E(k_min_u32), E(k_min3_f32), E(k_med3_f32), E(k_mul_legacy), E(k_rsq_f32), E(k_div_scale), E(k_div_fmas), E(k_div_fixup), E(k_cmp_class), E(k_mul_sgpr), E(k_fma_sgpr), E(k_sub_sgpr), E(t_sqrt_add7), E(t_sqrt_add15), E(t_sqrt_add31), E(t_sqrt3_add13), E(t_sqrt2_add30), E(l_b128_uniform), E(l_b128_perlane), E(x_pk2_add2), E(x_pk1_add3), E(x_pk3_add1), E(x_pk2_cmp2), E(x_pkfma2_add2), E(x_sqrt_pk3), E(m_cmp_add3), E(m_cmp2_add2), E(m_cmp3_add1), E(m_sqrt_add3), E(m_sqrt_cmp_add2), E(m_sqrt_cmp3), E(m_min_cnd_mul_fma), E(m_fma3_cmp), E(m_min_add3), E(m_cnd_add3), E(m_add_mul), E(k_ashr_i32), E(k_lshr_b32), E(k_lshl_b32), E(k_sub_u32), E(k_xor_b32), E(k_or_b32), E(k_bfe_u32), E(k_add3_u32), E(k_and_or_b32), E(k_fmac_f32), E(k_add_f32_neg), E(k_sub_f32), E(k_add_f32_abs), E(k_addc_co), E(k_subb_co), E(k_add_co), E(k_max_u32), E(k_med3_u32), E(k_min_i32), E(k_bfi_b32), E(k_perm_b32), E(k_mul_u32_u24), E(k_mad_u32_u24), E(k_xad_u32), E(k_cmp_lt_u32), E(k_sqrt_add_mix), E(k_cmp_add_mix), E(k_ldexp_f32), E(k_frexp_mant)};
 	int wavesPerSimd = argc > 1 ? atoi(argv[1]) : 8;
 	int blocks = 256 * wavesPerSimd;   // 256 CUs x (wavesPerSimd*4 waves / 4 waves per block)
 	float *out;
