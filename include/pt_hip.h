@@ -135,8 +135,13 @@ int pt_image_read_u8(pt_ctx *ctx, const void *d_image, int width, int height, un
  *         correctly-rounded sqrt differs from sqrtf inside its stated domain) << 32
  *         | #patterns where their guarded sqrt differs from sqrtf anywhere
  *   op 5: same ranges: out_u64[i] = #patterns where the kernels' short reciprocal differs from 1.0f / x
- *   op 6: b[i] pseudo-random (num, den) pairs from seed a[i], 2^-80 <= num < 2^80, 2^-40 <= den < 2^40:
- *         out_u64[i] = #pairs where the scan's short divide differs from num / den */
+ *   op 6: same ranges (positive normal floats >= 2^-96): out_u64[i] = #patterns where raw v_sqrt_f32 is one ulp
+ *         above the correctly rounded root | (#patterns one ulp below) << 32 — a histogram, no pass/fail
+ *   op 7: b[i] (num, den) pairs from seed a[i] — the first 16 the corners of the range, the rest pseudo-random with
+ *         2^-80 <= num < 2^80, 2^-40 <= den < 2^40: out_u64[i] = #pairs where the scan's short divide differs
+ *         from num / den | (#pairs compared) << 32
+ *   op 8: as op 7 for the bare num * v_rcp_f32(den) — the canary that the comparison can fail
+ *   op 9: pow5 of the float with bit pattern a[i] -> out_f[i]   (src/cl/ray.cl:61 pow(1 - cosTheta, 5)) */
 int pt_selftest(pt_ctx *ctx, int op, const uint64_t *a, const uint64_t *b, const float *in_f,
                 int n, uint64_t *out_u64, float *out_f);
 

@@ -289,3 +289,77 @@ void pto_postprocess(const float *image, int pixels, unsigned char *out) {
 			out[3 * (size_t)i + c] = (unsigned char)(int)(x * 255);
 		}
 }
+
+/* ---- exhaustive-check helpers (test infrastructure for tests/test_rng_exhaustive.py, tests/test_pow5_exhaustive.py
+ * and the GPU pow5 test).  Nothing below restates reference code; these are arbiters. ---- */
+
+/* States lo <= s < hi: how often does rand_float's narrowed float, computed with the reference's f64 DIVIDE
+ * (pto_rand_float above, src/cl/rng.cl:13), differ from the same state times RN(1/2147483647.0) — the form the HIP
+ * kernels use (pathtracer_amd/csrc/pt_device.h rand_float).  `s` is the state AFTER the update, i.e. the value
+ * that is converted. */
+uint64_t pto_rand_float_mul_mismatches(uint64_t lo, uint64_t hi) {
+	const double inv = 1.0 / 2147483647.0;
+	uint64_t bad = 0;
+	for(uint64_t s = lo; s < hi; s++) {
+		float a = (float)((double)s / 2147483647.0);
+		float b = (float)((double)s * inv);
+		uint32_t ua, ub;
+		memcpy(&ua, &a, 4); memcpy(&ub, &b, 4);
+		bad += ua != ub;
+	}
+	return bad;
+}
+
+/* The correctly rounded binary32 value of x^5, by exact integer arithmetic (a 24-bit significand to the fifth power
+ * has at most 120 bits: unsigned __int128), round-to-nearest-even into normal or denormal binary32. */
+typedef unsigned __int128 u128_t;
+static float pow5_exact(float x) {
+	if(x == 0 || isnan(x) || isinf(x)) return x * x * x * x * x;
+	int neg = x < 0, e;
+	float fr = frexpf(fabsf(x), &e);                 /* |x| = fr * 2^e, fr in [0.5, 1) */
+	uint32_t m = (uint32_t)ldexpf(fr, 24);            /* |x| = m * 2^(e-24), exact */
+	int E = 5 * (e - 24);
+	u128_t p = (u128_t)m * m; p *= m; p *= m; p *= m;
+	int top = 127;
+	while(!((p >> top) & 1)) top--;
+	int lead = top + E, keep = 24;
+	if(lead > 127) return neg ? -INFINITY : INFINITY;
+	if(lead < -126) keep = 24 - (-126 - lead);        /* denormal result: fewer bits kept */
+	float r;
+	if(keep < 0) r = 0.0f;
+	else if(keep == 0) {                              /* value in [2^-150, 2^-149): a tie only at exactly 2^-150 */
+		u128_t rest = p & ((((u128_t)1) << top) - 1);
+		r = rest ? ldexpf(1.0f, -149) : 0.0f;
+	} else {
+		int drop = top + 1 - keep;
+		u128_t q = drop > 0 ? p >> drop : p << -drop;
+		if(drop > 0) {
+			u128_t rem = p & ((((u128_t)1) << drop) - 1), half = ((u128_t)1) << (drop - 1);
+			if(rem > half || (rem == half && (q & 1))) q++;
+		}
+		r = ldexpf((float)(uint64_t)q, E + drop);     /* q <= 2^24: exact; overflow to inf is the correct rounding */
+	}
+	return neg ? -r : r;
+}
+
+/* out[i] = exact-arbiter x^5 of the float with bit pattern bits[i] */
+void pto_pow5_exact(const uint32_t *bits, long n, float *out) {
+	for(long i = 0; i < n; i++) { float x; memcpy(&x, &bits[i], 4); out[i] = pow5_exact(x); }
+}
+
+/* All 2^23 significands at biased exponent `expfield`: mismatches against the arbiter of
+ * which = 0: pow_f(x, 5) above — what the oracle's reflectance() calls (libm pow in f64, narrowed);
+ * which = 1: the three-multiply f64 chain the HIP kernels use (pt_device.h pow5), restated. */
+uint64_t pto_pow5_mismatches(int expfield, int which) {
+	uint64_t bad = 0;
+	for(uint32_t m = 0; m < (1u << 23); m++) {
+		uint32_t u = ((uint32_t)expfield << 23) | m, ua, ub;
+		float x; memcpy(&x, &u, 4);
+		float want = pow5_exact(x), got;
+		if(which == 0) got = pow_f(x, 5);
+		else { double d = (double)x, d2 = d * d, d4 = d2 * d2; got = (float)(d4 * d); }
+		memcpy(&ua, &want, 4); memcpy(&ub, &got, 4);
+		bad += ua != ub;
+	}
+	return bad;
+}

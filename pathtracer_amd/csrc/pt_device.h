@@ -34,7 +34,8 @@ PT_DEV float pt_div(float a, float b) { return a / b; }
 // its v_div_scale range scaling (exact powers of two, which change nothing while no intermediate leaves the normal
 // range: the smallest here is a residual, a multiple of ulp(den) * ulp(q) >= 2^-126) and without v_div_fixup (zeros,
 // infinities, NaNs, denormals: excluded).  8 VALU instructions instead of 11; pt_selftest op 7 compares it with the
-// compiler's divide on random operands of that range.
+// compiler's divide on pseudo-random operands of that range and on its corners (tests/test_gpu_parity.py::
+// test_short_divide_is_the_divide_on_its_range; op 8 is the canary: the bare num * v_rcp_f32(den) must FAIL there).
 PT_DEV float div_nt(float num, float den) {
 #if PT_FAST_MATH
 	return num * __builtin_amdgcn_rcpf(den);
@@ -142,8 +143,8 @@ PT_DEV uint32_t init_rng_2(uint32_t id, uint64_t xb) {
 
 // src/cl/rng.cl:11-14 — state = 16807*state % M; return (float)(state / 2147483647.0).
 // The state stays below 2^31, so the product stays below 2^46 and one fold is enough.
-// The f64 divide is replaced by a multiply with RN(1/M): tests/test_rng_exhaustive.py proves
-// (on the CPU, all 2^31 states) that the narrowed float is identical.
+// The f64 divide is replaced by a multiply with RN(1/M): tests/test_rng_exhaustive.py checks on the
+// CPU, for every one of the 2^31 - 1 states, that the narrowed float is identical.
 PT_DEV float rand_float(uint32_t &state) {
 	uint64_t p = (uint64_t)state * 16807u;
 	uint32_t t = (uint32_t)(p & PT_M31) + (uint32_t)(p >> 31);
@@ -168,8 +169,13 @@ PT_DEV f3 random_unit_vector(uint32_t &state) {
 // src/cl/ray.cl:54-56 — in - (normal*2)*dot(in,normal)
 PT_DEV f3 reflection_dir(f3 in, f3 n) { return sub3(in, scl3(scl3(n, 2.0f), dot3(in, n))); }
 
-// pow(x,5) of oracle/ref_shim.cpp = (float)pow((double)x,5.0): x^5 in f64 (x^2 exact, two
-// roundings after) narrowed to f32 — identical except on a ~2^-29 double-rounding sliver.
+// pow(x,5) of oracle/ref_shim.cpp = (float)pow((double)x,5.0).  Here: x^5 in f64 (x^2 exact, two roundings
+// after) narrowed to f32.  Both are the CORRECTLY ROUNDED binary32 value of the exact x^5 for every float x:
+// checked against an exact 128-bit integer arbiter on all 2^23 mantissas of a normal binade (the chain and
+// binary32 rounding are invariant under powers of two while the result is a normal float), on every float whose
+// x^5 is a binary32 denormal or rounds to zero, and across the overflow edge — tests/test_pow5_exhaustive.py
+// (host libm and the chain, CPU) and tests/test_gpu_parity.py::test_pow5_is_correctly_rounded (this function,
+// on the device).  No double-rounding case exists.
 PT_DEV float pow5(float x) {
 #if PT_FAST_MATH
 	const float x2 = x * x;

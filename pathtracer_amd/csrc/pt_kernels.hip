@@ -108,6 +108,36 @@ __global__ void pt_selftest_kernel(int op, const uint64_t *a, const uint64_t *b,
 			if(raw < want) lo++;
 		}
 		ou[i] = hi + (lo << 32);
+	} else if(op == 7 || op == 8) {
+		// b[i] pseudo-random (num, den) pairs from seed a[i], 2^-80 <= num <= 2^80, 2^-40 <= den <= 2^40 (finish_scan's
+		// guarantee), the first 16 pairs of every item the corners of that range: how many have div_nt(num, den)
+		// (op 7) or the bare num * v_rcp_f32(den) (op 8, the canary: it must fail) != num / den.  High half: pairs compared.
+		uint64_t bad = 0, done = 0;
+		uint64_t st = a[i] * 0x9E3779B97F4A7C15ull + 0xD1B54A32D192ED03ull;
+		for(uint64_t k = 0; k < b[i]; k++) {
+			float num, den;
+			if(k < 16) {
+				const float ncorner[4] = {0x1p-80f, 0x1p80f, 0x1.fffffep-80f * 2.0f, 0x1.fffffep79f};
+				const float dcorner[4] = {0x1p-40f, 0x1p40f, 0x1.fffffep-40f * 2.0f, 0x1.fffffep39f};
+				num = ncorner[k & 3]; den = dcorner[k >> 2];
+			} else {
+				st = st * 6364136223846793005ull + 1442695040888963407ull;
+				const uint32_t r1 = (uint32_t)(st >> 32);
+				st = st * 6364136223846793005ull + 1442695040888963407ull;
+				const uint32_t r2 = (uint32_t)(st >> 32);
+				// exponent fields 127-80 .. 127+79 (160 binades) and 127-40 .. 127+39 (80 binades), any mantissa
+				num = __uint_as_float(((47u + (r1 >> 23) % 160u) << 23) | (r1 & 0x7fffffu));
+				den = __uint_as_float(((87u + (r2 >> 23) % 80u) << 23) | (r2 & 0x7fffffu));
+			}
+			const float want = num / den;
+			const float got = op == 7 ? div_nt(num, den) : num * __builtin_amdgcn_rcpf(den);
+			if(__float_as_uint(got) != __float_as_uint(want)) bad++;
+			done++;
+		}
+		ou[i] = bad + (done << 32);
+	} else if(op == 9) {
+		// pow5 of the float with bit pattern a[i] -> of[i] (tests compare with an exact integer arbiter on the host)
+		of[i] = pow5(__uint_as_float((uint32_t)a[i]));
 	}
 }
 
@@ -161,6 +191,8 @@ extern "C" int pt_device_count(int *count) {
 	return PT_OK;
 }
 
+extern "C" int pt_ctx_destroy(pt_ctx *c);
+
 extern "C" int pt_ctx_create(int device, pt_ctx **out) {
 	if(!out) return fail(PT_E_INVALID, "pt_ctx_create: NULL out%s", NULL);
 	*out = NULL;
@@ -171,12 +203,22 @@ extern "C" int pt_ctx_create(int device, pt_ctx **out) {
 	pt_ctx *c = (pt_ctx *)calloc(1, sizeof(pt_ctx));
 	if(!c) return fail(PT_E_NOMEM, "pt_ctx_create: host allocation failed%s", NULL);
 	c->device = device;
-	HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-	HIP_TRY(hipMalloc((void **)&c->counter, sizeof(unsigned long long)));
-	HIP_TRY(hipMalloc((void **)&c->queue, 256));
-	HIP_TRY(hipEventCreate(&c->evStart));
-	HIP_TRY(hipEventCreate(&c->evStop));
-	for(int i = 0; i < 2 * PT_TIMING_SLOTS; i++) HIP_TRY(hipEventCreate(&c->ring[i]));
+	// every step after the calloc: on failure the half-built context is torn down again (pt_ctx_destroy copes with
+	// the members that are still NULL) and the first error is what the caller sees
+	hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+	const char *what = "hipStreamCreateWithFlags";
+	if(e == hipSuccess) { e = hipMalloc((void **)&c->counter, sizeof(unsigned long long)); what = "hipMalloc(counter)"; }
+	if(e == hipSuccess) { e = hipMalloc((void **)&c->queue, 256); what = "hipMalloc(queue)"; }
+	if(e == hipSuccess) { e = hipEventCreate(&c->evStart); what = "hipEventCreate"; }
+	if(e == hipSuccess) { e = hipEventCreate(&c->evStop); what = "hipEventCreate"; }
+	for(int i = 0; e == hipSuccess && i < 2 * PT_TIMING_SLOTS; i++) { e = hipEventCreate(&c->ring[i]); what = "hipEventCreate(ring)"; }
+	if(e != hipSuccess) {
+		char msg[256];
+		snprintf(msg, sizeof msg, "%s failed: %s", what, hipGetErrorString(e));
+		pt_ctx_destroy(c);
+		snprintf(g_err, sizeof g_err, "pt_ctx_create: %s", msg);
+		return e == hipErrorOutOfMemory ? PT_E_NOMEM : PT_E_DEVICE;
+	}
 	*out = c;
 	return PT_OK;
 }
@@ -184,14 +226,15 @@ extern "C" int pt_ctx_create(int device, pt_ctx **out) {
 extern "C" int pt_ctx_destroy(pt_ctx *c) {
 	if(!c) return PT_OK;
 	(void)hipSetDevice(c->device);
-	(void)hipStreamSynchronize(c->stream);
+	if(c->stream) (void)hipStreamSynchronize(c->stream);
 	(void)hipFree(c->image); (void)hipFree(c->geom); (void)hipFree(c->matA); (void)hipFree(c->matB);
 	(void)hipFree(c->seedmul); (void)hipFree(c->counter); (void)hipFree(c->queue);
 	(void)hipFree(c->dCellStart); (void)hipFree(c->dItems); (void)hipFree(c->dBig);
 	free(c->hostSpheres); (void)hipFree(c->u8);
-	(void)hipEventDestroy(c->evStart); (void)hipEventDestroy(c->evStop);
-	for(int i = 0; i < 2 * PT_TIMING_SLOTS; i++) (void)hipEventDestroy(c->ring[i]);
-	(void)hipStreamDestroy(c->stream);
+	if(c->evStart) (void)hipEventDestroy(c->evStart);
+	if(c->evStop) (void)hipEventDestroy(c->evStop);
+	for(int i = 0; i < 2 * PT_TIMING_SLOTS; i++) if(c->ring[i]) (void)hipEventDestroy(c->ring[i]);
+	if(c->stream) (void)hipStreamDestroy(c->stream);
 	free(c->hostSeedmul);
 	free(c);
 	return PT_OK;
@@ -238,7 +281,9 @@ extern "C" int pt_scene_upload(pt_ctx *c, const float *spheres, int n) {
 		// r*r is rounded once here exactly as `sphere.radius * sphere.radius` is per test (src/cl/ray.cl:75)
 		volatile float r2 = r[3] * r[3];
 		hg[i] = make_float4(r[0], r[1], r[2], r2);
-		int type = (int)r[4];
+		// material codes outside 0..3 match no branch of src/cl/ray.cl:130-171 (the ray is left as it is): one code, -1,
+		// for all of them, which shade_hit() handles together with the back face of a light
+		int type = (r[4] > -1.0f && r[4] < 4.0f) ? (int)r[4] : -1;
 		float tb;
 		memcpy(&tb, &type, 4);
 		ha[i] = make_float4(r[5], r[6], r[7], tb);
@@ -274,7 +319,7 @@ static int grow_int(int **d, size_t *cap, size_t need) {
 	return PT_OK;
 }
 
-static int build_grid(pt_ctx *c) {
+static int build_grid(pt_ctx *c, hipStream_t st) {
 	const int n = c->nSpheres;
 	const float4 *sp = c->hostSpheres;
 	std::vector<char> isBig((size_t)n, 0);
@@ -366,9 +411,11 @@ static int build_grid(pt_ctx *c) {
 	if((rc = grow_int(&c->dCellStart, &c->capCells, cellStart.size() + 1)) != PT_OK) return rc;
 	if((rc = grow_int(&c->dItems, &c->capItems, items.size() + 1)) != PT_OK) return rc;
 	if((rc = grow_int(&c->dBig, &c->capBig, big.size() + 1)) != PT_OK) return rc;
-	HIP_TRY(hipMemcpy(c->dCellStart, cellStart.data(), sizeof(int) * cellStart.size(), hipMemcpyHostToDevice));
-	if(!items.empty()) HIP_TRY(hipMemcpy(c->dItems, items.data(), sizeof(int) * items.size(), hipMemcpyHostToDevice));
-	if(!big.empty()) HIP_TRY(hipMemcpy(c->dBig, big.data(), sizeof(int) * big.size(), hipMemcpyHostToDevice));
+	// on the stream the render will be launched on (ordered before it), drained before the host vectors go away
+	HIP_TRY(hipMemcpyAsync(c->dCellStart, cellStart.data(), sizeof(int) * cellStart.size(), hipMemcpyHostToDevice, st));
+	if(!items.empty()) HIP_TRY(hipMemcpyAsync(c->dItems, items.data(), sizeof(int) * items.size(), hipMemcpyHostToDevice, st));
+	if(!big.empty()) HIP_TRY(hipMemcpyAsync(c->dBig, big.data(), sizeof(int) * big.size(), hipMemcpyHostToDevice, st));
+	HIP_TRY(hipStreamSynchronize(st));
 	G.cellStart = c->dCellStart; G.items = c->dItems; G.big = c->dBig;
 	c->grid = G;
 	c->gridBuilt = true;
@@ -406,21 +453,131 @@ static bool camera_is_enclosed(const pt_ctx *c, const float *pos) {
 	return true;
 }
 
-extern "C" int pt_render(pt_ctx *c, const pt_render_args *a) {
-	if(!c || !a) return fail(PT_E_INVALID, "pt_render: NULL%s", NULL);
+// Where one render call keeps its device-side working memory (the kernels take these pointers as arguments).
+struct RenderScratch {
+	const uint64_t *seedmul;
+	unsigned long long *counter;
+	unsigned int *queue;
+};
+
+static int check_render_args(const pt_ctx *c, const pt_render_args *a, const char *who) {
+	if(!c || !a) return fail(PT_E_INVALID, "%s: NULL", who);
 	if(a->width <= 0 || a->height <= 0 || a->max_depth < 0 || a->n_frames < 0 || a->first_frame < 0)
-		return fail(PT_E_INVALID, "pt_render: bad image/sample arguments%s", NULL);
-	if((long long)a->width * a->height > (1ll << 30)) return fail(PT_E_INVALID, "pt_render: image too large%s", NULL);
-	if(a->accel != 0 && a->accel != 1) return fail(PT_E_INVALID, "pt_render: unknown accel%s", NULL);
+		return fail(PT_E_INVALID, "%s: bad image/sample arguments", who);
+	if((long long)a->width * a->height > (1ll << 30)) return fail(PT_E_INVALID, "%s: image too large", who);
+	if(a->accel != 0 && a->accel != 1) return fail(PT_E_INVALID, "%s: unknown accel", who);
 	if(a->world < 1 || a->rank < 0 || a->rank >= a->world || a->band_rows < 1)
-		return fail(PT_E_INVALID, "pt_render: bad partition (rank/world/band_rows)%s", NULL);
-	if(a->n_frames > 0 && !a->seeds) return fail(PT_E_INVALID, "pt_render: NULL seeds%s", NULL);
-	float4 *img = (float4 *)a->d_image;
-	if(!img) {
-		if(!c->image || c->imgW != a->width || c->imgH != a->height)
-			return fail(PT_E_STATE, "pt_render: no accumulator of this size (call pt_image_alloc)%s", NULL);
-		img = c->image;
+		return fail(PT_E_INVALID, "%s: bad partition (rank/world/band_rows)", who);
+	if(a->n_frames > 0 && !a->seeds) return fail(PT_E_INVALID, "%s: NULL seeds", who);
+	if(!a->d_image && (!c->image || c->imgW != a->width || c->imgH != a->height))
+		return fail(PT_E_STATE, "%s: no accumulator of this size (call pt_image_alloc)", who);
+	return PT_OK;
+}
+
+// Kernel choice, launch geometry and the launch itself, allocates nothing.
+static int launch_frames(pt_ctx *c, const pt_render_args *a, float4 *img, hipStream_t st, const RenderScratch &rs, bool useGrid) {
+	KParams p;
+	p.W = a->width; p.H = a->height; p.maxDepth = a->max_depth; p.n = c->nSpheres;
+	p.bgx = a->background[0]; p.bgy = a->background[1]; p.bgz = a->background[2];
+	p.px = a->cam_pos[0]; p.py = a->cam_pos[1]; p.pz = a->cam_pos[2];
+	// cos/sin of the launch-uniform camera angles: the host libm, as the oracle uses (src/cl/ray.cl:45-49)
+	p.cosRx = cosf(a->cam_rot[0]); p.sinRx = sinf(a->cam_rot[0]);
+	p.cosRy = cosf(a->cam_rot[1]); p.sinRy = sinf(a->cam_rot[1]);
+	p.sensorWidth = a->sensor_width; p.focalLength = a->focal_length; p.aperture = a->aperture; p.exposure = a->exposure;
+	p.firstFrame = a->first_frame; p.nFrames = a->n_frames;
+	p.rank = a->rank; p.world = a->world; p.bandRows = a->band_rows;
+	const long long lp = (long long)local_rows(a->height, a->rank, a->world, a->band_rows) * a->width;
+	p.localPixels = (int)lp;
+	if(lp == 0) return PT_OK;
+
+	SceneTables sc = {c->geom, c->matA, c->matB};
+	// LDS kernel: enough lanes per pixel that the launch has about a dozen rounds of the chip's 8192 wave
+	// slots, at most 16 (measured: the 1080p headline frame 243 ms at 1 lane per pixel, 231 ms at 4; one rank's eighth
+	// of it 32.9 / 28.6 / 26.1 / 25.0 / 24.4 ms at 1 / 2 / 4 / 8 / 16 lanes, 25.1 ms at 32)
+	p.logS = 0;
+	{
+		const char *fs = getenv("PT_LANES_PER_PIXEL");      // debugging aid: force 1, 2, 4 or 8
+		int want = 0;
+		if(fs) { int v = atoi(fs); while((1 << want) < v && want < 5) want++; }
+		else {
+			while(want < 2 && (2 << want) <= a->n_frames) want++;      // 4 lanes whatever the frame size (4K: 734 -> 727 ms)
+			while(want < 4 && (lp << want) < 64ll * 12 * 8192 && (2 << want) <= a->n_frames) want++;
+		}
+		if((long long)a->first_frame + a->n_frames >= (1 << 24)) want = 0;      // the group accumulation counts frames in float
+		p.logS = want;
 	}
+	// LDS kernel: trios of the table that hold a sphere much smaller than the largest one get a wave-level "can any
+	// lane hit it" test per sphere before the sqrt/select part (closest_hit_lds); a pure speed heuristic, same image.
+	// The mask has 32 bits: trios beyond the first 32 (tables above 96 spheres, reachable only with PT_KERNEL=lds —
+	// the lock-step kernel is chosen for at most 64) always take the unconditional path: correct, only slower.
+	p.trioSkipMask = 0;
+	if(c->hostSpheres && !getenv("PT_NO_TRIO_SKIP")) {
+		float rmax = 0.0f;
+		for(int i = 0; i < c->nSpheres; i++) rmax = fmaxf(rmax, fabsf(c->hostSpheres[i].w));
+		for(int i = 0; i < c->nSpheres && i < 96 && i / 3 < c->nSpheres / 3; i++)
+			if(fabsf(c->hostSpheres[i].w) < rmax * 0.125f) p.trioSkipMask |= 1u << (i / 3);
+	}
+	LaunchArgs la;
+	la.image = img; la.p = p; la.sc = sc; la.seedmul = rs.seedmul; la.bounceCounter = rs.counter; la.queue = rs.queue;
+	la.stream = st; la.count = a->bounce_count != NULL;
+	la.gridPixels = (unsigned)(((lp << p.logS) + 255) / 256);
+	// Up to PT_LOCKSTEP_MAX_SPHERES spheres: the lock-step kernel with the whole table in LDS and a branch-free
+	// scan (the reference's own scene has 9).  Beyond that the persistent streaming kernel wins on open scenes even
+	// where the table would still fit in LDS, because paths end after a few bounces and its lanes never idle (1080p,
+	// 500 random spheres: 40.7 ms lock-step, 7.6 ms streaming).  In a CLOSED scene paths run to the depth limit, no
+	// lane idles, and the lock-step kernel stays ahead up to about a hundred spheres (39 spheres in the box: 72 vs
+	// 97 ms; 137: 58 vs 55 ms; 355: 175 vs 117 ms): it is chosen up to PT_LOCKSTEP_MAX_CLOSED when rays from the
+	// camera in all 26 axis and diagonal directions hit something.  Either kernel gives the same image.
+	const char *force = getenv("PT_KERNEL");      // debugging aid: "stream" or "lds" overrides the choice
+	la.kernel = c->nSpheres <= PT_LOCKSTEP_MAX_SPHERES ? PT_K_LDS : PT_K_STREAM;
+	if(la.kernel == PT_K_STREAM && c->nSpheres <= PT_LOCKSTEP_MAX_CLOSED && camera_is_enclosed(c, a->cam_pos)) la.kernel = PT_K_LDS;
+	if(force && strcmp(force, "stream") == 0 && c->nSpheres > 0) la.kernel = PT_K_STREAM;
+	if(force && strcmp(force, "lds") == 0 && c->nSpheres <= PT_LDS_MAX_SPHERES) la.kernel = PT_K_LDS;
+	memset(&la.grid, 0, sizeof la.grid);
+	if(useGrid) { la.grid = c->grid; la.kernel = PT_K_GRID; }
+	la.ldsBytes = la.kernel == PT_K_LDS ? pt_strict::lds_table_bytes(c->nSpheres) : 0;
+	// streaming kernel: persistent one-wave blocks, at most 32 per CU; surplus pixels come through the queue
+	const long long swaves = (lp + 63) / 64;
+	la.gridStream = (unsigned)(swaves < 256 * 32 ? swaves : 256 * 32);
+	// float rules: strict (bit-identical to the oracle) unless the caller, or PT_MATH=fast, asks for the relaxed build
+	bool fast = a->fast_math != 0;
+	const char *math = getenv("PT_MATH");
+	if(math && strcmp(math, "fast") == 0) fast = true;
+	if(math && strcmp(math, "strict") == 0) fast = false;
+
+	if(la.kernel == PT_K_STREAM || la.kernel == PT_K_GRID) HIP_TRY(hipMemsetAsync(rs.queue, 0, 256, st));     // before the start event: not kernel time
+	if(a->bounce_count) {
+		HIP_TRY(hipMemsetAsync(rs.counter, 0, sizeof(unsigned long long), st));
+		if(fast) pt_fast::launch_render(la); else pt_strict::launch_render(la);
+		HIP_TRY(hipGetLastError());
+		unsigned long long v = 0;
+		HIP_TRY(hipMemcpyAsync(&v, rs.counter, sizeof v, hipMemcpyDeviceToHost, st));
+		HIP_TRY(hipStreamSynchronize(st));
+		*a->bounce_count = (uint64_t)v;
+		return PT_OK;
+	}
+	const bool ringTimed = a->record_timing && !a->kernel_ms;
+	if(ringTimed && c->nTimed >= PT_TIMING_SLOTS)
+		return fail(PT_E_STATE, "pt_render: timing ring full (call pt_kernel_times)%s", NULL);
+	if(a->kernel_ms) HIP_TRY(hipEventRecord(c->evStart, st));
+	if(ringTimed) HIP_TRY(hipEventRecord(c->ring[2 * c->nTimed], st));
+	if(fast) pt_fast::launch_render(la); else pt_strict::launch_render(la);
+	HIP_TRY(hipGetLastError());
+	if(ringTimed) { HIP_TRY(hipEventRecord(c->ring[2 * c->nTimed + 1], st)); c->nTimed++; }
+	if(a->kernel_ms) {
+		HIP_TRY(hipEventRecord(c->evStop, st));
+		HIP_TRY(hipEventSynchronize(c->evStop));
+		HIP_TRY(hipEventElapsedTime(a->kernel_ms, c->evStart, c->evStop));
+		return PT_OK;
+	}
+	if(!a->async) HIP_TRY(hipStreamSynchronize(st));
+	return PT_OK;
+}
+
+extern "C" int pt_render(pt_ctx *c, const pt_render_args *a) {
+	int rc = check_render_args(c, a, "pt_render");
+	if(rc != PT_OK) return rc;
+	float4 *img = a->d_image ? (float4 *)a->d_image : c->image;
 	HIP_TRY(hipSetDevice(c->device));
 	hipStream_t st = a->stream ? (hipStream_t)a->stream : c->stream;
 	if(a->n_frames == 0) return PT_OK;
@@ -448,109 +605,15 @@ extern "C" int pt_render(pt_ctx *c, const pt_render_args *a) {
 		HIP_TRY(e0); HIP_TRY(e1); HIP_TRY(ec); HIP_TRY(es);
 	}
 
-	KParams p;
-	p.W = a->width; p.H = a->height; p.maxDepth = a->max_depth; p.n = c->nSpheres;
-	p.bgx = a->background[0]; p.bgy = a->background[1]; p.bgz = a->background[2];
-	p.px = a->cam_pos[0]; p.py = a->cam_pos[1]; p.pz = a->cam_pos[2];
-	// cos/sin of the launch-uniform camera angles: the host libm, as the oracle uses (src/cl/ray.cl:45-49)
-	p.cosRx = cosf(a->cam_rot[0]); p.sinRx = sinf(a->cam_rot[0]);
-	p.cosRy = cosf(a->cam_rot[1]); p.sinRy = sinf(a->cam_rot[1]);
-	p.sensorWidth = a->sensor_width; p.focalLength = a->focal_length; p.aperture = a->aperture; p.exposure = a->exposure;
-	p.firstFrame = a->first_frame; p.nFrames = a->n_frames;
-	p.rank = a->rank; p.world = a->world; p.bandRows = a->band_rows;
-	long long lp = (long long)local_rows(a->height, a->rank, a->world, a->band_rows) * a->width;
-	p.localPixels = (int)lp;
-	if(lp == 0) return PT_OK;
-
-	SceneTables sc = {c->geom, c->matA, c->matB};
-	// LDS kernel: enough lanes per pixel that the launch has about a dozen rounds of the chip's 8192 wave
-	// slots, at most 16 (measured: the 1080p headline frame 243 ms at 1 lane per pixel, 231 ms at 4; one rank's eighth
-	// of it 32.9 / 28.6 / 26.1 / 25.0 / 24.4 ms at 1 / 2 / 4 / 8 / 16 lanes, 25.1 ms at 32)
-	p.logS = 0;
-	{
-		const char *fs = getenv("PT_LANES_PER_PIXEL");      // debugging aid: force 1, 2, 4 or 8
-		int want = 0;
-		if(fs) { int v = atoi(fs); while((1 << want) < v && want < 5) want++; }
-		else {
-			while(want < 2 && (2 << want) <= a->n_frames) want++;      // 4 lanes whatever the frame size (4K: 734 -> 727 ms)
-			while(want < 4 && (lp << want) < 64ll * 12 * 8192 && (2 << want) <= a->n_frames) want++;
-		}
-		if((long long)a->first_frame + a->n_frames >= (1 << 24)) want = 0;      // the group accumulation counts frames in float
-		p.logS = want;
-	}
-	// LDS kernel: trios of the table that hold a sphere much smaller than the largest one get a wave-level "can any
-	// lane hit it" test per sphere before the sqrt/select part (closest_hit_lds); a pure speed heuristic, same image.
-	p.trioSkipMask = 0;
-	if(c->hostSpheres && !getenv("PT_NO_TRIO_SKIP")) {
-		float rmax = 0.0f;
-		for(int i = 0; i < c->nSpheres; i++) rmax = fmaxf(rmax, fabsf(c->hostSpheres[i].w));
-		for(int i = 0; i < c->nSpheres && i < 96 && i / 3 < c->nSpheres / 3; i++)
-			if(fabsf(c->hostSpheres[i].w) < rmax * 0.125f) p.trioSkipMask |= 1u << (i / 3);
-	}
-	LaunchArgs la;
-	la.image = img; la.p = p; la.sc = sc; la.seedmul = c->seedmul; la.bounceCounter = c->counter; la.queue = c->queue;
-	la.stream = st; la.count = a->bounce_count != NULL;
-	la.gridPixels = (unsigned)(((lp << p.logS) + 255) / 256);
-	// Up to PT_LOCKSTEP_MAX_SPHERES spheres: the lock-step kernel with the whole table in LDS and a branch-free
-	// scan (the reference's own scene has 9).  Beyond that the persistent streaming kernel wins on open scenes even
-	// where the table would still fit in LDS, because paths end after a few bounces and its lanes never idle (1080p,
-	// 500 random spheres: 40.7 ms lock-step, 7.6 ms streaming).  In a CLOSED scene paths run to the depth limit, no
-	// lane idles, and the lock-step kernel stays ahead up to about a hundred spheres (39 spheres in the box: 72 vs
-	// 97 ms; 137: 58 vs 55 ms; 355: 175 vs 117 ms): it is chosen up to PT_LOCKSTEP_MAX_CLOSED when rays from the
-	// camera in all 26 axis and diagonal directions hit something.  Either kernel gives the same image.
-	const char *force = getenv("PT_KERNEL");      // debugging aid: "stream" or "lds" overrides the choice
-	la.kernel = c->nSpheres <= PT_LOCKSTEP_MAX_SPHERES ? PT_K_LDS : PT_K_STREAM;
-	if(la.kernel == PT_K_STREAM && c->nSpheres <= PT_LOCKSTEP_MAX_CLOSED && camera_is_enclosed(c, a->cam_pos)) la.kernel = PT_K_LDS;
-	if(force && strcmp(force, "stream") == 0 && c->nSpheres > 0) la.kernel = PT_K_STREAM;
-	if(force && strcmp(force, "lds") == 0 && c->nSpheres <= PT_LDS_MAX_SPHERES) la.kernel = PT_K_LDS;
 	// opt-in acceleration structure (no reference counterpart): same closest hit, found through a uniform grid
 	bool accel = a->accel == 1;
 	const char *acc = getenv("PT_ACCEL");
 	if(acc && strcmp(acc, "grid") == 0) accel = true;
 	if(acc && strcmp(acc, "none") == 0) accel = false;
-	memset(&la.grid, 0, sizeof la.grid);
-	if(accel && c->nSpheres > 0) {
-		if(!c->gridBuilt) { int rc = build_grid(c); if(rc != PT_OK) return rc; }
-		la.grid = c->grid;
-		la.kernel = PT_K_GRID;
-	}
-	la.ldsBytes = la.kernel == PT_K_LDS ? pt_strict::lds_table_bytes(c->nSpheres) : 0;
-	// streaming kernel: persistent one-wave blocks, at most 32 per CU; surplus pixels come through the queue
-	const long long swaves = (lp + 63) / 64;
-	la.gridStream = (unsigned)(swaves < 256 * 32 ? swaves : 256 * 32);
-	// float rules: strict (bit-identical to the oracle) unless the caller, or PT_MATH=fast, asks for the relaxed build
-	bool fast = a->fast_math != 0;
-	const char *math = getenv("PT_MATH");
-	if(math && strcmp(math, "fast") == 0) fast = true;
-	if(math && strcmp(math, "strict") == 0) fast = false;
-
-	if(la.kernel == PT_K_STREAM || la.kernel == PT_K_GRID) HIP_TRY(hipMemsetAsync(c->queue, 0, 256, st));     // before the start event: not kernel time
-	if(a->bounce_count) {
-		HIP_TRY(hipMemsetAsync(c->counter, 0, sizeof(unsigned long long), st));
-		if(fast) pt_fast::launch_render(la); else pt_strict::launch_render(la);
-		HIP_TRY(hipGetLastError());
-		unsigned long long v = 0;
-		HIP_TRY(hipMemcpyAsync(&v, c->counter, sizeof v, hipMemcpyDeviceToHost, st));
-		HIP_TRY(hipStreamSynchronize(st));
-		*a->bounce_count = (uint64_t)v;
-		return PT_OK;
-	}
-	const bool ringTimed = a->record_timing && !a->kernel_ms;
-	if(ringTimed && c->nTimed >= PT_TIMING_SLOTS)
-		return fail(PT_E_STATE, "pt_render: timing ring full (call pt_kernel_times)%s", NULL);
-	if(a->kernel_ms) HIP_TRY(hipEventRecord(c->evStart, st));
-	if(ringTimed) HIP_TRY(hipEventRecord(c->ring[2 * c->nTimed], st));
-	if(fast) pt_fast::launch_render(la); else pt_strict::launch_render(la);
-	HIP_TRY(hipGetLastError());
-	if(ringTimed) { HIP_TRY(hipEventRecord(c->ring[2 * c->nTimed + 1], st)); c->nTimed++; }
-	if(a->kernel_ms) {
-		HIP_TRY(hipEventRecord(c->evStop, st));
-		HIP_TRY(hipEventSynchronize(c->evStop));
-		HIP_TRY(hipEventElapsedTime(a->kernel_ms, c->evStart, c->evStop));
-		return PT_OK;
-	}
-	if(!a->async) HIP_TRY(hipStreamSynchronize(st));
-	return PT_OK;
+	accel = accel && c->nSpheres > 0;
+	if(accel && !c->gridBuilt) { rc = build_grid(c, st); if(rc != PT_OK) return rc; }
+	const RenderScratch rs = {c->seedmul, c->counter, c->queue};
+	return launch_frames(c, a, img, st, rs, accel);
 }
 
 extern "C" int pt_kernel_times(pt_ctx *c, float *ms, int cap, int *n) {
@@ -606,7 +669,7 @@ extern "C" int pt_image_read_u8(pt_ctx *c, const void *d_image, int width, int h
 
 extern "C" int pt_selftest(pt_ctx *c, int op, const uint64_t *a, const uint64_t *b, const float *in_f, int n,
                            uint64_t *out_u64, float *out_f) {
-	if(!c || n <= 0 || op < 0 || op > 6) return fail(PT_E_INVALID, "pt_selftest: bad arguments%s", NULL);
+	if(!c || n <= 0 || op < 0 || op > 9) return fail(PT_E_INVALID, "pt_selftest: bad arguments%s", NULL);
 	HIP_TRY(hipSetDevice(c->device));
 	uint64_t *da = NULL, *db = NULL, *dou = NULL;
 	float *dif = NULL, *dof = NULL;

@@ -73,9 +73,11 @@ PT_DEV bool shade_hit(Path &pt, float t, const float4 g, const float4 mA, const 
 	const f3 offPos = sub3(hitPos, scl3(normal, 0.0001f));                               // ray.cl:119 (outward normal)
 	bool front = true;
 	if(dot3(d, normal) > 0.0f) { front = false; normal = scl3(normal, -1.0f); }          // ray.cl:122-128
-	if(type == 0) {                                                                      // ray.cl:130-134
-		if(front) { color = mul3(pt.mask, mcol); return true; }
-		return false;                                                                    // back face of a light: the ray is left as it is
+	if(type <= 0) {                                                                      // ray.cl:130-134
+		if(front && type == 0) { color = mul3(pt.mask, mcol); return true; }
+		// back face of a light, or a material code none of ray.cl:130-171's branches matches (the table holds -1
+		// for those, pt_scene_upload): the ray is left as it is, nothing is drawn from the RNG
+		return false;
 	}
 	if(!front && type != 3) return false;                                                // ray.cl:137,144: only the dielectric scatters from a back face
 	// The three scattering materials all end in `direction = base + random_unit_vector * scale` with the SAME two

@@ -160,6 +160,10 @@ def material_micro(kind):
         "metal_fuzz25": metal(0.9, 0.7, 0.5, 0.6, 2.0 ** 25),
         "metal_fuzz70": metal(0.9, 0.7, 0.5, 0.6, 2.0 ** 70),
         "dielectric_idx30": dielectric(0.6, 0.9, 0.7, 0.5, 0.1, 2.0 ** 30),
+        # a material code that none of the kernel's branches matches (/root/reference/src/cl/ray.cl:130-171; the code
+        # comes straight from the Lua table, lua_wrapper.c:41-42): the ray is left as it is and re-hits until the depth runs out
+        "unknown7": (7, 0.9, 0.1, 0.1, 0.5, 0.1, 1.5),
+        "unknown_neg": (-2, 0.9, 0.1, 0.1, 0.5, 0.1, 1.5),
     }
     s = [
         _sphere(0, 0, -6, 1.5, mats[kind]),

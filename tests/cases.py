@@ -35,5 +35,8 @@ CASES = {
     "metal_fuzz25_48x36": (lambda: scenes.material_micro("metal_fuzz25"), 48, 36, 50, 4),
     "metal_fuzz70_48x36": (lambda: scenes.material_micro("metal_fuzz70"), 48, 36, 50, 4),
     "dielectric_idx30_48x36": (lambda: scenes.material_micro("dielectric_idx30"), 48, 36, 50, 4),
+    # material codes outside 0..3: no branch of ray.cl:130-171 matches, no RNG draw, black after maxDepth re-hits
+    "unknown7_48x36": (lambda: scenes.material_micro("unknown7"), 48, 36, 50, 4),
+    "unknown_neg_48x36": (lambda: scenes.material_micro("unknown_neg"), 48, 36, 50, 4),
     "one_pixel": (lambda: scenes.main_lua_frame(0), 1, 1, 50, 4),           # id 0: RNG stuck at 0
 }

@@ -65,8 +65,9 @@ def test_divide_sqrt_correctly_rounded(ctx, oracle):
     _, of = ctx.selftest(3, in_f=np.stack([c, r], axis=1).reshape(-1), n=n)
     of = of.reshape(n, 4)
     want = np.asarray([oracle.reflectance(float(a), float(b)) for a, b in zip(c[:20000], r[:20000])], np.float32)
-    # pow(x,5) goes through f64 on both sides; a double-rounding sliver (p ~ 2^-29) is tolerated
-    assert (bits(of[:20000, 2]) != bits(want)).sum() <= 1
+    # pow(x,5): libm on the oracle's side, an f64 product chain on the device — both correctly rounded for every
+    # float (tests/test_pow5_exhaustive.py, test_pow5_is_correctly_rounded below): no tolerance
+    assert np.array_equal(bits(of[:20000, 2]), bits(want))
 
 
 def test_short_sqrt_is_sqrtf_on_every_float(ctx):
@@ -93,11 +94,44 @@ def test_short_reciprocal_is_the_divide_on_every_float(ctx):
 
 def test_short_divide_is_the_divide_on_its_range(ctx):
     """finish_scan's divide (pt_device.h div_nt: the compiler's expansion without range scaling and special-case
-    fix-up) against the compiler's correctly rounded divide on 2^32 pseudo-random operand pairs of the range the scan
-    guarantees, plus the corners of that range, on the device."""
-    n = 1 << 16
-    ou, _ = ctx.selftest(6, a=np.arange(n, dtype=np.uint64), b=np.full(n, 1 << 16, np.uint64))
-    assert int(ou.sum()) == 0, "div_nt != / somewhere"
+    fix-up) against the compiler's correctly rounded divide on 2^32 operand pairs of the range the scan guarantees
+    (2^-80 <= num <= 2^80, 2^-40 <= den <= 2^40: pseudo-random, plus the 16 corners per work item), on the device
+    (pt_selftest op 7).  Not vacuous: the op reports how many pairs it compared, and the same comparison FAILS for
+    the bare num * v_rcp_f32(den) (op 8)."""
+    n, per = 1 << 16, 1 << 16
+    a, b = np.arange(n, dtype=np.uint64), np.full(n, per, np.uint64)
+    ou, _ = ctx.selftest(7, a=a, b=b)
+    assert int((ou >> np.uint64(32)).sum()) == n * per, "op 7 compared %d pairs, expected %d" % (int((ou >> np.uint64(32)).sum()), n * per)
+    assert int((ou & np.uint64(0xFFFFFFFF)).sum()) == 0, "div_nt != / on %d pairs" % int((ou & np.uint64(0xFFFFFFFF)).sum())
+    ou, _ = ctx.selftest(8, a=a[:256], b=b[:256])
+    assert int((ou >> np.uint64(32)).sum()) == 256 * per
+    bad = int((ou & np.uint64(0xFFFFFFFF)).sum())
+    assert bad > 256 * per // 100, "canary: num * rcp(den) should differ from the divide on a good share of the pairs, got %d" % bad
+
+
+def test_pow5_is_correctly_rounded(ctx, oracle):
+    """pt_device.h pow5 on the device against the exact integer arbiter (oracle/pt_oracle.c pow5_exact) on every input
+    class of tests/test_pow5_exhaustive.py: all 2^23 significands of three normal binades, every float whose x^5 is a
+    binary32 denormal or rounds to zero, the overflow edge, zero and denormal x.  Zero tolerance."""
+    import ctypes as C
+    from test_pow5_exhaustive import EXP_FIELDS
+    f = oracle.lib.pto_pow5_exact
+    f.argtypes = [C.POINTER(C.c_uint32), C.c_long, C.POINTER(C.c_float)]
+    mant = np.arange(1 << 23, dtype=np.uint32)
+    for e in EXP_FIELDS:
+        xb = (np.uint32(e) << np.uint32(23)) | mant
+        _, of = ctx.selftest(9, a=xb.astype(np.uint64))
+        want = np.empty(len(xb), np.float32)
+        f(xb.ctypes.data_as(C.POINTER(C.c_uint32)), len(xb), want.ctypes.data_as(C.POINTER(C.c_float)))
+        ne = bits(of[:len(xb)]) != bits(want)
+        assert not ne.any(), "exponent field %d: %d mismatches, first x bits 0x%08x" % (e, int(ne.sum()), int(xb[np.argmax(ne)]))
+    # negative x and the specials
+    xb = np.asarray([0x80000000, 0xbf800000, 0xc0490fdb, 0x7f800000, 0xff800000, 0x7fc00000, 0x00000001, 0x807fffff], np.uint32)
+    _, of = ctx.selftest(9, a=xb.astype(np.uint64))
+    want = np.empty(len(xb), np.float32)
+    f(xb.ctypes.data_as(C.POINTER(C.c_uint32)), len(xb), want.ctypes.data_as(C.POINTER(C.c_float)))
+    nan = np.isnan(want)
+    assert np.array_equal(np.isnan(of[:len(xb)]), nan) and np.array_equal(bits(of[:len(xb)])[~nan], bits(want)[~nan])
 
 
 def test_kernel_timing_ring(ctx):

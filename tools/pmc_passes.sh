@@ -14,6 +14,14 @@ passes=(
  "FETCH_SIZE"
  "WRITE_SIZE"
 )
+# PT_PMC_EXTRA=1: the memory-side passes (L2 hit/miss, L1 -> L2 requests and their latency, LDS activity)
+if [ "${PT_PMC_EXTRA:-0}" = "1" ]; then
+passes+=(
+ "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_READ_sum"
+ "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_PENDING_STALL_CYCLES_sum"
+ "SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INST_LEVEL_VMEM SQ_INSTS_LDS_LOAD"
+)
+fi
 i=0
 for p in "${passes[@]}"; do
   i=$((i+1))
