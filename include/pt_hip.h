@@ -106,6 +106,22 @@ int pt_scene_upload(pt_ctx *ctx, const float *spheres, int n);
  * clSetKernelArg ×7 + clEnqueueNDRangeKernel + clFinish (src/c/renderer.c:159-179,251). */
 int pt_render(pt_ctx *ctx, const pt_render_args *args);
 
+/* pt_render for callers that cannot allocate: code under HIP graph capture, tight serving loops, harnesses that
+ * forbid hipMalloc.  NO COUNTERPART IN THE REFERENCE (its host allocates a sphere buffer per render(),
+ * src/c/renderer.c:155).  Same arguments, same kernels, same image as pt_render, but the call makes no hipMalloc,
+ * hipFree or host allocation: the working memory pt_render keeps in buffers of the context (the per-sample seed
+ * table, the streaming kernel's pixel-queue head, the bounce counter) lives in a file-scope device array of
+ * 512 + 8 * PT_NOALLOC_MAX_FRAMES bytes (33 280 B) that every GPU the library runs on holds until the process
+ * ends; the seeds reach it as kernel arguments.  The caller still passes the scene (pt_scene_upload, beforehand)
+ * and the accumulator (args->d_image, or the context's own from pt_image_alloc).
+ * Limits, rejected with PT_E_INVALID and a message: n_frames <= PT_NOALLOC_MAX_FRAMES per call (continue with
+ * first_frame for more); accel must be 0 (building the grid allocates; PT_ACCEL is ignored here).
+ * All contexts on one GPU share that GPU's array: two pt_render_noalloc calls that overlap in time on the same
+ * GPU (different streams or threads) race on it.  Calls in sequence are safe; each call re-initialises what it
+ * needs (queue head and counter are cleared, the seed table is rewritten). */
+#define PT_NOALLOC_MAX_FRAMES 4096
+int pt_render_noalloc(pt_ctx *ctx, const pt_render_args *args);
+
 /* Durations (ms) of the render kernels launched with record_timing since the last call, oldest first:
  * waits for those launches, writes up to `cap` values to ms[], stores the count in *n and empties the
  * ring.  No reference counterpart (the reference times with gettimeofday around its loop,

@@ -142,6 +142,27 @@ __global__ void pt_selftest_kernel(int op, const uint64_t *a, const uint64_t *b,
 }
 
 // ---------------------------------------------------------------------------------------
+// Scratch of pt_render_noalloc (include/pt_hip.h): what pt_render keeps in hipMalloc'ed buffers of the context —
+// the pixel-queue head of the streaming kernel, the bounce counter, the per-sample seed table — lives here
+// instead, one copy per GPU for the life of the process.  The NAME is only a host-side handle: the device
+// address comes from hipGetSymbolAddress (pt_ctx_create), and only that pointer is ever handed to a kernel,
+// a memset or a copy.
+// ---------------------------------------------------------------------------------------
+#define PT_SCRATCH_QUEUE_OFF 0                    // unsigned int, streaming kernel's queue head (256 B line of its own)
+#define PT_SCRATCH_COUNTER_OFF 256                // unsigned long long, bounce counter (line of its own)
+#define PT_SCRATCH_SEEDS_OFF 512                  // uint64_t[PT_NOALLOC_MAX_FRAMES]: 16807 * seed_k
+#define PT_SCRATCH_BYTES (PT_SCRATCH_SEEDS_OFF + 8 * PT_NOALLOC_MAX_FRAMES)
+static __device__ __align__(256) unsigned char scratch[PT_SCRATCH_BYTES];
+
+// Host seeds -> the scratch seed table without any staging allocation: up to 256 seeds ride in the kernel
+// arguments (2 KB by value), the kernel folds the sample-uniform 16807 * seed (src/cl/rng.cl:8) and stores them.
+struct SeedChunk { uint64_t v[256]; };
+__global__ __launch_bounds__(256) void pt_stage_seeds_kernel(const SeedChunk ch, int count, uint64_t *__restrict__ dst) {
+	const int i = (int)threadIdx.x;
+	if(i < count) dst[i] = 16807ull * ch.v[i];
+}
+
+// ---------------------------------------------------------------------------------------
 // Host side of the C ABI
 // ---------------------------------------------------------------------------------------
 static thread_local char g_err[512] = "";
@@ -178,6 +199,7 @@ struct pt_ctx {
 	hipEvent_t evStart, evStop;
 	hipEvent_t ring[2 * PT_TIMING_SLOTS];   // start/stop pairs of launches made with record_timing
 	int nTimed;
+	unsigned char *scratchPtr;    // device address of `scratch` on this context's GPU (hipGetSymbolAddress)
 };
 
 extern "C" const char *pt_last_error(void) { return g_err; }
@@ -212,6 +234,8 @@ extern "C" int pt_ctx_create(int device, pt_ctx **out) {
 	if(e == hipSuccess) { e = hipEventCreate(&c->evStart); what = "hipEventCreate"; }
 	if(e == hipSuccess) { e = hipEventCreate(&c->evStop); what = "hipEventCreate"; }
 	for(int i = 0; e == hipSuccess && i < 2 * PT_TIMING_SLOTS; i++) { e = hipEventCreate(&c->ring[i]); what = "hipEventCreate(ring)"; }
+	// this GPU's copy of the no-allocation scratch: its device address, looked up with this device current
+	if(e == hipSuccess) { e = hipGetSymbolAddress((void **)&c->scratchPtr, HIP_SYMBOL(scratch)); what = "hipGetSymbolAddress(scratch)"; }
 	if(e != hipSuccess) {
 		char msg[256];
 		snprintf(msg, sizeof msg, "%s failed: %s", what, hipGetErrorString(e));
@@ -453,7 +477,8 @@ static bool camera_is_enclosed(const pt_ctx *c, const float *pos) {
 	return true;
 }
 
-// Where one render call keeps its device-side working memory (the kernels take these pointers as arguments).
+// Where one render call keeps its device-side working memory: the context's hipMalloc'ed buffers (pt_render) or
+// this GPU's copy of `scratch` (pt_render_noalloc).  The kernels take these pointers as arguments either way.
 struct RenderScratch {
 	const uint64_t *seedmul;
 	unsigned long long *counter;
@@ -474,7 +499,7 @@ static int check_render_args(const pt_ctx *c, const pt_render_args *a, const cha
 	return PT_OK;
 }
 
-// Kernel choice, launch geometry and the launch itself, allocates nothing.
+// Kernel choice, launch geometry and the launch itself, shared by pt_render and pt_render_noalloc.  Allocates nothing.
 static int launch_frames(pt_ctx *c, const pt_render_args *a, float4 *img, hipStream_t st, const RenderScratch &rs, bool useGrid) {
 	KParams p;
 	p.W = a->width; p.H = a->height; p.maxDepth = a->max_depth; p.n = c->nSpheres;
@@ -614,6 +639,34 @@ extern "C" int pt_render(pt_ctx *c, const pt_render_args *a) {
 	if(accel && !c->gridBuilt) { rc = build_grid(c, st); if(rc != PT_OK) return rc; }
 	const RenderScratch rs = {c->seedmul, c->counter, c->queue};
 	return launch_frames(c, a, img, st, rs, accel);
+}
+
+// pt_render for callers that cannot allocate (include/pt_hip.h).  Same kernels, same image; the working memory is
+// this GPU's `scratch` array, reached through the pointer pt_ctx_create looked up.  No hipMalloc / hipFree /
+// malloc here or below: the seeds travel as kernel arguments, everything else is a launch, a memset or an event.
+extern "C" int pt_render_noalloc(pt_ctx *c, const pt_render_args *a) {
+	int rc = check_render_args(c, a, "pt_render_noalloc");
+	if(rc != PT_OK) return rc;
+	if(a->n_frames > PT_NOALLOC_MAX_FRAMES)
+		return fail(PT_E_INVALID, "pt_render_noalloc: n_frames exceeds PT_NOALLOC_MAX_FRAMES (4096) — split the call or use pt_render%s", NULL);
+	if(a->accel != 0) return fail(PT_E_INVALID, "pt_render_noalloc: accel=1 builds a grid, which allocates — use pt_render%s", NULL);
+	if(!c->scratchPtr) return fail(PT_E_STATE, "pt_render_noalloc: no scratch address on this context%s", NULL);
+	float4 *img = a->d_image ? (float4 *)a->d_image : c->image;
+	HIP_TRY(hipSetDevice(c->device));
+	hipStream_t st = a->stream ? (hipStream_t)a->stream : c->stream;
+	if(a->n_frames == 0) return PT_OK;
+	unsigned char *const sp = c->scratchPtr;      // the device address, never the array's name
+	uint64_t *const dSeeds = (uint64_t *)(sp + PT_SCRATCH_SEEDS_OFF);
+	for(int k0 = 0; k0 < a->n_frames; k0 += 256) {
+		SeedChunk ch;
+		const int cnt = a->n_frames - k0 < 256 ? a->n_frames - k0 : 256;
+		for(int k = 0; k < cnt; k++) ch.v[k] = a->seeds[k0 + k];
+		for(int k = cnt; k < 256; k++) ch.v[k] = 0;
+		hipLaunchKernelGGL(pt_stage_seeds_kernel, dim3(1), dim3(256), 0, st, ch, cnt, dSeeds + k0);
+		HIP_TRY(hipGetLastError());
+	}
+	const RenderScratch rs = {dSeeds, (unsigned long long *)(sp + PT_SCRATCH_COUNTER_OFF), (unsigned int *)(sp + PT_SCRATCH_QUEUE_OFF)};
+	return launch_frames(c, a, img, st, rs, false);
 }
 
 extern "C" int pt_kernel_times(pt_ctx *c, float *ms, int cap, int *n) {

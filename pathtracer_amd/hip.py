@@ -42,7 +42,7 @@ _lib = None
 
 # every symbol include/pt_hip.h declares
 EXPORTS = ["pt_last_error", "pt_device_count", "pt_ctx_create", "pt_ctx_destroy", "pt_image_alloc",
-           "pt_scene_upload", "pt_render", "pt_kernel_times", "pt_sync", "pt_image_read", "pt_image_read_u8", "pt_selftest"]
+           "pt_scene_upload", "pt_render", "pt_render_noalloc", "pt_kernel_times", "pt_sync", "pt_image_read", "pt_image_read_u8", "pt_selftest"]
 
 
 def load():
@@ -60,6 +60,7 @@ def load():
     lib.pt_image_alloc.argtypes = [C.c_void_p, C.c_int, C.c_int]
     lib.pt_scene_upload.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_int]
     lib.pt_render.argtypes = [C.c_void_p, C.POINTER(RenderArgs)]
+    lib.pt_render_noalloc.argtypes = [C.c_void_p, C.POINTER(RenderArgs)]
     lib.pt_kernel_times.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_int)]
     lib.pt_sync.argtypes = [C.c_void_p]
     lib.pt_image_read.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
@@ -114,7 +115,8 @@ class Context:
         _check(self.lib.pt_scene_upload(self.h, sp.ctypes.data_as(C.POINTER(C.c_float)), sp.shape[0]), "pt_scene_upload")
 
     def render(self, scene, width, height, max_depth, seeds, first_frame=0, rank=0, world=1, band_rows=16,
-               d_image=None, stream=None, count_bounces=False, async_=False, time_kernel=False, record_timing=False, fast_math=False, accel=0):
+               d_image=None, stream=None, count_bounces=False, async_=False, time_kernel=False, record_timing=False, fast_math=False, accel=0,
+               noalloc=False):
         """scene: dict with 'bg' and 'cam' (pathtracer_amd.scenes layout); the spheres must have
         been uploaded with scene_upload().  Returns the bounce count (count_bounces) or the
         HIP-event kernel time in ms (time_kernel) if asked, else None."""
@@ -140,7 +142,10 @@ class Context:
         a.record_timing = 1 if record_timing else 0
         a.fast_math = 1 if fast_math else 0
         a.accel = int(accel)
-        _check(self.lib.pt_render(self.h, C.byref(a)), "pt_render")
+        if noalloc:
+            _check(self.lib.pt_render_noalloc(self.h, C.byref(a)), "pt_render_noalloc")
+        else:
+            _check(self.lib.pt_render(self.h, C.byref(a)), "pt_render")
         if time_kernel:
             return float(ms.value)
         return int(bc.value) if count_bounces else None
