@@ -147,9 +147,10 @@ int pt_image_read_u8(pt_ctx *ctx, const void *d_image, int width, int height, un
  *   op 1: state a[i]: rand_float                  -> out_u64[i]=state, out_f[i] (src/cl/rng.cl:11-14)
  *   op 2: state a[i]: random_unit_vector          -> out_u64[i]=state, out_f[3i..] (src/cl/rng.cl:20-34)
  *   op 3: in_f[2i]=x, in_f[2i+1]=y: x/y, sqrt(x), reflectance(x,y), pow5(x) -> out_f[4i..]
- *   op 4: float bit patterns a[i] .. a[i]+b[i]-1: out_u64[i] = (#patterns where the kernels' short
- *         correctly-rounded sqrt differs from sqrtf inside its stated domain) << 32
- *         | #patterns where their guarded sqrt differs from sqrtf anywhere
+ *   op 4: float bit patterns a[i] .. a[i]+b[i]-1, the kernels' short correctly-rounded sqrt forms against sqrtf:
+ *         out_u64[i] = #patterns where the fully guarded form differs anywhere
+ *         | (#patterns where the +-0/inf-guarded form differs inside its stated domain) << 21
+ *         | (#patterns where the unguarded forms differ inside their stated domains) << 42
  *   op 5: same ranges: out_u64[i] = #patterns where the kernels' short reciprocal differs from 1.0f / x
  *   op 6: same ranges (positive normal floats >= 2^-96): out_u64[i] = #patterns where raw v_sqrt_f32 is one ulp
  *         above the correctly rounded root | (#patterns one ulp below) << 32 — a histogram, no pass/fail
@@ -157,7 +158,11 @@ int pt_image_read_u8(pt_ctx *ctx, const void *d_image, int width, int height, un
  *         2^-80 <= num < 2^80, 2^-40 <= den < 2^40: out_u64[i] = #pairs where the scan's short divide differs
  *         from num / den | (#pairs compared) << 32
  *   op 8: as op 7 for the bare num * v_rcp_f32(den) — the canary that the comparison can fail
- *   op 9: pow5 of the float with bit pattern a[i] -> out_f[i]   (src/cl/ray.cl:61 pow(1 - cosTheta, 5)) */
+ *   op 9: pow5 of the float with bit pattern a[i] -> out_f[i]   (src/cl/ray.cl:61 pow(1 - cosTheta, 5))
+ *   op 10: as op 7 for the lock-step kernel's form of the divide: den = a = |d|^2 formed from x = dot(d, d) as the
+ *         kernel forms it (src/cl/ray.cl:73), the reciprocal seeded with v_rsq_f32(x)^2
+ *   op 11: same ranges as op 4: out_u64[i] = #patterns x where normalize()'s 1 / length (one v_rsq_f32 for root and
+ *         reciprocal) differs from 1.0f / sqrtf(x) */
 int pt_selftest(pt_ctx *ctx, int op, const uint64_t *a, const uint64_t *b, const float *in_f,
                 int n, uint64_t *out_u64, float *out_f);
 

@@ -36,17 +36,21 @@ PT_DEV float pt_div(float a, float b) { return a / b; }
 // infinities, NaNs, denormals: excluded).  8 VALU instructions instead of 11; pt_selftest op 7 compares it with the
 // compiler's divide on pseudo-random operands of that range and on its corners (tests/test_gpu_parity.py::
 // test_short_divide_is_the_divide_on_its_range; op 8 is the canary: the bare num * v_rcp_f32(den) must FAIL there).
-PT_DEV float div_nt(float num, float den) {
+PT_DEV float div_seeded(float num, float den, float r) {
 #if PT_FAST_MATH
-	return num * __builtin_amdgcn_rcpf(den);
+	return num * r;
 #else
-	float r = __builtin_amdgcn_rcpf(den);
 	r = __builtin_fmaf(__builtin_fmaf(-den, r, 1.0f), r, r);
 	float q = num * r;
 	q = __builtin_fmaf(__builtin_fmaf(-den, q, num), r, q);
 	return __builtin_fmaf(__builtin_fmaf(-den, q, num), r, q);
 #endif
 }
+PT_DEV float div_nt(float num, float den) { return div_seeded(num, den, __builtin_amdgcn_rcpf(den)); }
+// The same divide where den = a = RN(RN(sqrt(x))^2) is the scan's |d|^2 (src/cl/ray.cl:73) and y = v_rsq_f32(x) is already
+// in a register (sqrt_pos_y below): y * y approximates 1 / a to about 2^-21, which the Newton step of div_seeded squares
+// away — one multiply instead of the quarter-rate v_rcp_f32.  pt_selftest op 10 compares it with the compiler's divide.
+PT_DEV float div_by_a(float num, float a, float y) { return div_seeded(num, a, y * y); }
 
 PT_DEV f3 mk3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
 PT_DEV f3 add3(f3 a, f3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
@@ -56,35 +60,62 @@ PT_DEV f3 scl3(f3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
 // OpenCL dot/length/normalize as pinned in oracle/ref_shim.cpp
 PT_DEV float dot3(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
 
-// Correctly rounded sqrt without the small-input rescaling of the compiler's expansion: v_sqrt_f32
-// (1 ulp) then the two neighbours are tried with an exact FMA residual.  Identical to sqrtf() for
-// x == +-0, every |x| >= 2^-96 (negative: NaN), +inf and NaN — pt_selftest op 4 checks every such
-// bit pattern on the device.  For 0 < |x| < 2^-96 it is not: the residual may underflow and
-// v_sqrt_f32 flushes denormal inputs (a negative denormal gives -0, not NaN).  Callers either know x
-// cannot be there or use sqrt_cr() below.  8 instead of 15 VALU operations after v_sqrt_f32.
+// Correctly rounded sqrt in FIVE instructions: y = v_rsq_f32(x) (1 ulp), g = x * y, h = y / 2, then one Markstein
+// step  s = fma(fma(-g, g, x), h, g).  Identical to sqrtf() for every x with 2^-96 <= x < +inf — pt_selftest op 4
+// walks every such bit pattern on the device (tools/probe/sqrt_probe.hip is where the sequence was found: the raw
+// v_sqrt_f32 is one ulp low on 15 % of the floats and one ulp high on 1e5 of them, so the compiler's expansion, and
+// round 1's sqrt_nt, test both neighbours with an FMA residual each: 8 instructions after the v_sqrt_f32).
+// A negative or NaN x gives NaN, as sqrtf.  NOT sqrtf for x = +-0 and +inf (0 * inf: NaN) and for 0 < x < 2^-96
+// (residual underflow, v_rsq_f32 flushes denormals): sqrt_pos() is for callers that cannot see those inputs or do not
+// care what they give; sqrt_z() adds +-0 and +inf; sqrt_cr() is sqrtf for every input.
 constexpr uint32_t PT_SQRT_TINY_BITS = 0x0f800000u;   // 2^-96
-PT_DEV float sqrt_nt(float x) {
-	float s = __builtin_amdgcn_sqrtf(x);
+PT_DEV float sqrt_pos_y(float x, float &y) {
 #if PT_FAST_MATH
-	return s;
+	y = __builtin_amdgcn_rsqf(x);
+	return __builtin_amdgcn_sqrtf(x);
+#else
+	y = __builtin_amdgcn_rsqf(x);
+	const float g = x * y, h = 0.5f * y;
+	return __builtin_fmaf(__builtin_fmaf(-g, g, x), h, g);
 #endif
-	float sm = __uint_as_float(__float_as_uint(s) - 1u);
-	float sp = __uint_as_float(__float_as_uint(s) + 1u);
-	float rm = __builtin_fmaf(-sm, s, x);
-	float rp = __builtin_fmaf(-sp, s, x);
-	s = rm <= 0.0f ? sm : s;
-	s = rp > 0.0f ? sp : s;
+}
+PT_DEV float sqrt_pos(float x) {
+#if PT_FAST_MATH
+	return __builtin_amdgcn_sqrtf(x);
+#else
+	float y;
+	return sqrt_pos_y(x, y);
+#endif
+}
+
+// sqrt_pos plus x = +-0 and +inf (returned as they are, as sqrtf does): sqrtf for x == +-0, every |x| >= 2^-96
+// (negative: NaN), +inf and NaN.
+PT_DEV float sqrt_z(float x) {
+	float s = sqrt_pos(x);
+#if !PT_FAST_MATH
+	if(__builtin_isfpclass(x, 0x0260)) s = x;      // fcZero | fcPosInf: one v_cmp_class_f32 + one v_cndmask_b32
+#endif
 	return s;
 }
 
-// sqrtf() for every input: the short form where it is exact, the compiler's full expansion in the
-// (practically never taken) branch for 0 < x < 2^-96.
+// sqrt_pos for 1 - c*c with |c| <= 1 (random_unit_vector): the argument is 0 or at least 2^-24, and the NaN that
+// sqrt_pos gives at 0 becomes the 0 it should be through one v_max_f32 (IEEE maximum: the non-NaN operand).
+PT_DEV float sqrt_01(float x) {
+	float s = sqrt_pos(x);
+#if !PT_FAST_MATH
+	asm("v_max_f32 %0, %1, 0" : "=v"(s) : "v"(s));
+#endif
+	return s;
+}
+
+// sqrtf() for every input: the short form where it is exact, the compiler's full expansion in the (practically never
+// taken) branch for everything else: +-0, 0 < |x| < 2^-96, negative, +inf, NaN.
 PT_DEV float sqrt_cr(float x) {
-	float s = sqrt_nt(x);
+	float s = sqrt_pos(x);
 #if PT_FAST_MATH
 	return s;
 #endif
-	if(__builtin_expect((__float_as_uint(x) & 0x7fffffffu) - 1u < PT_SQRT_TINY_BITS - 1u, 0)) s = sqrtf(x);
+	if(__builtin_expect(__float_as_uint(x) - PT_SQRT_TINY_BITS >= 0x7f800000u - PT_SQRT_TINY_BITS, 0)) s = sqrtf(x);
 	return s;
 }
 
@@ -110,17 +141,28 @@ PT_DEV float rcp_cr(float x) {
 	return r;
 }
 
-// normalize() = a * (1 / length(a)) (oracle/ref_shim.cpp): the short sqrt and the short reciprocal under ONE guard.
-// x = dot(a, a) in [2^-96, 2^127] puts sqrt_nt in its exact domain and the length in [2^-48, 2^63.5], well inside
-// rcp_nt's; everything else (0, tiny, huge, inf, NaN) takes the compiler's correctly rounded forms.
-PT_DEV f3 norm3(f3 a) {
-	const float x = dot3(a, a);
-	float inv = rcp_nt(sqrt_nt(x));
-#if !PT_FAST_MATH
-	if(__builtin_expect(__float_as_uint(x) - PT_SQRT_TINY_BITS > 0x7f000000u - PT_SQRT_TINY_BITS, 0)) inv = 1.0f / sqrtf(x);
+// normalize() = a * (1 / length(a)) (oracle/ref_shim.cpp): the short sqrt and the short reciprocal under ONE guard,
+// with ONE transcendental: the v_rsq_f32 of the sqrt, moved up by one ulp, is also the seed of the reciprocal of the
+// rounded length (within 2^-22 of it; the two Newton steps of rcp_nt land on the correctly rounded quotient from there as
+// they do from v_rcp_f32 — pt_selftest op 11 walks every x = dot(a, a) of the guarded range against 1.0f / sqrtf(x)).
+// The extra ulp matters for the 222 values of x just under a power of four: the root is 2^k (1 - 2^-24), its reciprocal
+// rounds to 2^-k (1 + 2^-23), and a seed of exactly 2^-k is a fixed point of the step (tools/probe/invlen_probe.hip).
+// x in [2^-96, 2^127] puts sqrt_pos in its exact domain and the length in [2^-48, 2^63.5], well inside rcp_nt's;
+// everything else (0, tiny, huge, inf, NaN) takes the compiler's correctly rounded forms.
+PT_DEV float inv_len(float x) {
+#if PT_FAST_MATH
+	return __builtin_amdgcn_rsqf(x);
+#else
+	float r;
+	const float s = sqrt_pos_y(x, r);
+	r = __uint_as_float(__float_as_uint(r) + 1u);
+	r = __builtin_fmaf(__builtin_fmaf(-s, r, 1.0f), r, r);
+	r = __builtin_fmaf(__builtin_fmaf(-s, r, 1.0f), r, r);
+	if(__builtin_expect(__float_as_uint(x) - PT_SQRT_TINY_BITS > 0x7f000000u - PT_SQRT_TINY_BITS, 0)) r = 1.0f / sqrtf(x);
+	return r;
 #endif
-	return scl3(a, inv);
 }
+PT_DEV f3 norm3(f3 a) { return scl3(a, inv_len(dot3(a, a))); }
 
 constexpr uint32_t PT_M31 = 2147483647u;   // MINSTD modulus 2^31 - 1 (src/cl/rng.cl:12)
 
@@ -160,9 +202,9 @@ PT_DEV float rand_pm1(uint32_t &state) { return -1.0f + rand_float(state) * 2.0f
 PT_DEV f3 random_unit_vector(uint32_t &state) {
 	float cosTheta = rand_pm1(state);
 	float cosPhi = rand_pm1(state);
-	// 1 - c*c with |c| <= 1 is 0 or >= 2^-24 (c*c is a float below 1 or exactly 1): sqrt_nt is exact
-	float sinTheta = sqrt_nt(1.0f - cosTheta * cosTheta);
-	float sinPhi = sqrt_nt(1.0f - cosPhi * cosPhi);
+	// 1 - c*c with |c| <= 1 is 0 or >= 2^-24 (c*c is a float below 1 or exactly 1)
+	float sinTheta = sqrt_01(1.0f - cosTheta * cosTheta);
+	float sinPhi = sqrt_01(1.0f - cosPhi * cosPhi);
 	return mk3(sinTheta * cosPhi, sinTheta * sinPhi, cosTheta);
 }
 
@@ -200,7 +242,7 @@ PT_DEV f3 refraction_dir(f3 in, f3 n, float rel) {
 	float cosTheta = fminf(dot3(scl3(in, -1.0f), n), 1.0f);
 	f3 perp = scl3(add3(in, scl3(n, cosTheta)), rel);
 	float lp = len3(perp);
-	f3 par = scl3(n, -sqrt_nt(fabsf(1.0f - lp * lp)));      // 1 - lp*lp is 0 or at least 2^-24 in magnitude: sqrt_nt is exact
+	f3 par = scl3(n, -sqrt_z(fabsf(1.0f - lp * lp)));       // 1 - lp*lp is 0, inf, or at least 2^-24 in magnitude
 	return add3(par, perp);
 }
 

@@ -72,20 +72,23 @@ __global__ void pt_selftest_kernel(int op, const uint64_t *a, const uint64_t *b,
 		of[4 * i + 2] = reflectance(x, schlick_r0(y));
 		of[4 * i + 3] = pow5(x);
 	} else if(op == 4) {
-		// bit patterns a[i] .. a[i] + b[i] - 1: how many have sqrt_cr != sqrtf, how many in sqrt_nt's
-		// stated domain (0, >= 2^-96, inf, NaN, negative) have sqrt_nt != sqrtf (NaN == NaN here)
-		uint64_t bad_cr = 0, bad_nt = 0;
+		// bit patterns a[i] .. a[i] + b[i] - 1 against sqrtf (NaN == NaN): bits 0-20 #sqrt_cr wrong anywhere; bits 21-41
+		// #sqrt_z wrong in its domain (+-0, |x| >= 2^-96, inf, NaN); bits 42-62 #sqrt_pos wrong in its domain
+		// (2^-96 <= x < inf, negative below -2^-96, NaN) or #sqrt_01 wrong on [2^-96, 1] and +-0
+		uint64_t bad_cr = 0, bad_z = 0, bad_pos = 0;
 		for(uint64_t k = 0; k < b[i]; k++) {
 			const uint32_t u = (uint32_t)(a[i] + k);
 			const float x = __uint_as_float(u);
 			const float want = sqrtf(x);
-			const float g1 = sqrt_cr(x), g2 = sqrt_nt(x);
 			const bool nanw = want != want;
-			if(nanw ? (g1 == g1) : (__float_as_uint(g1) != __float_as_uint(want))) bad_cr++;
-			const bool dom = !((u & 0x7fffffffu) - 1u < PT_SQRT_TINY_BITS - 1u);
-			if(dom && (nanw ? (g2 == g2) : (__float_as_uint(g2) != __float_as_uint(want)))) bad_nt++;
+			auto differs = [&](float g) { return nanw ? (g == g) : (__float_as_uint(g) != __float_as_uint(want)); };
+			if(differs(sqrt_cr(x))) bad_cr++;
+			const uint32_t mag = u & 0x7fffffffu;
+			if(!(mag - 1u < PT_SQRT_TINY_BITS - 1u) && differs(sqrt_z(x))) bad_z++;
+			if(mag >= PT_SQRT_TINY_BITS && mag != 0x7f800000u && differs(sqrt_pos(x))) bad_pos++;
+			if((u == 0u || u == 0x80000000u || (u >= PT_SQRT_TINY_BITS && u <= 0x3f800000u)) && __float_as_uint(sqrt_01(x)) != __float_as_uint(u == 0x80000000u ? 0.0f : want)) bad_pos++;
 		}
-		ou[i] = bad_cr + (bad_nt << 32);
+		ou[i] = bad_cr + (bad_z << 21) + (bad_pos << 42);
 	} else if(op == 5) {
 		// bit patterns a[i] .. a[i] + b[i] - 1: how many have rcp_cr(x) != 1.0f / x (NaN == NaN)
 		uint64_t bad = 0;
@@ -138,6 +141,43 @@ __global__ void pt_selftest_kernel(int op, const uint64_t *a, const uint64_t *b,
 	} else if(op == 9) {
 		// pow5 of the float with bit pattern a[i] -> of[i] (tests compare with an exact integer arbiter on the host)
 		of[i] = pow5(__uint_as_float((uint32_t)a[i]));
+	} else if(op == 10) {
+		// the lock-step scan's divide as the kernel forms it: x = dot(d, d) pseudo-random in [2^-40, 2^40] (16 corners
+		// first), ln = sqrt_pos_y(x, y), a = ln * ln, num pseudo-random in [2^-80, 2^80]: #pairs with
+		// div_by_a(num, a, y) != num / a | (#pairs compared) << 32
+		uint64_t bad = 0, done = 0;
+		uint64_t st = a[i] * 0x9E3779B97F4A7C15ull + 0xD1B54A32D192ED03ull;
+		for(uint64_t k = 0; k < b[i]; k++) {
+			float num, x;
+			if(k < 16) {
+				const float ncorner[4] = {0x1p-80f, 0x1p80f, 0x1.fffffep-80f * 2.0f, 0x1.fffffep79f};
+				const float dcorner[4] = {0x1p-40f, 0x1p40f, 0x1.fffffep-40f * 2.0f, 0x1.fffffep39f};
+				num = ncorner[k & 3]; x = dcorner[k >> 2];
+			} else {
+				st = st * 6364136223846793005ull + 1442695040888963407ull;
+				const uint32_t r1 = (uint32_t)(st >> 32);
+				st = st * 6364136223846793005ull + 1442695040888963407ull;
+				const uint32_t r2 = (uint32_t)(st >> 32);
+				num = __uint_as_float(((47u + (r1 >> 23) % 160u) << 23) | (r1 & 0x7fffffu));
+				x = __uint_as_float(((87u + (r2 >> 23) % 80u) << 23) | (r2 & 0x7fffffu));
+			}
+			float y;
+			const float ln = sqrt_pos_y(x, y);
+			const float den = ln * ln;
+			if(__float_as_uint(div_by_a(num, den, y)) != __float_as_uint(num / den)) bad++;
+			done++;
+		}
+		ou[i] = bad + (done << 32);
+	} else if(op == 11) {
+		// bit patterns a[i] .. a[i] + b[i] - 1: #patterns x where inv_len(x) (normalize()'s 1 / length from x = dot(v, v),
+		// one v_rsq_f32 for both the root and the reciprocal) != 1.0f / sqrtf(x)   (NaN == NaN)
+		uint64_t bad = 0;
+		for(uint64_t k = 0; k < b[i]; k++) {
+			const float x = __uint_as_float((uint32_t)(a[i] + k));
+			const float want = 1.0f / sqrtf(x), got = inv_len(x);
+			if(want != want ? (got == got) : (__float_as_uint(got) != __float_as_uint(want))) bad++;
+		}
+		ou[i] = bad;
 	}
 }
 
@@ -722,7 +762,7 @@ extern "C" int pt_image_read_u8(pt_ctx *c, const void *d_image, int width, int h
 
 extern "C" int pt_selftest(pt_ctx *c, int op, const uint64_t *a, const uint64_t *b, const float *in_f, int n,
                            uint64_t *out_u64, float *out_f) {
-	if(!c || n <= 0 || op < 0 || op > 9) return fail(PT_E_INVALID, "pt_selftest: bad arguments%s", NULL);
+	if(!c || n <= 0 || op < 0 || op > 11) return fail(PT_E_INVALID, "pt_selftest: bad arguments%s", NULL);
 	HIP_TRY(hipSetDevice(c->device));
 	uint64_t *da = NULL, *db = NULL, *dou = NULL;
 	float *dif = NULL, *dof = NULL;

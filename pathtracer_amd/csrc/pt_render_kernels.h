@@ -94,7 +94,9 @@ PT_DEV bool shade_hit(Path &pt, float t, const float4 g, const float4 mA, const 
 			float rel = mB.z, r0 = mB.w;                                                 // mB.w: Schlick r0 of refIdx, folded on the host
 			if(!front) { rel = pt_div(1.0f, mB.z); r0 = schlick_r0(rel); }               // ray.cl:152
 			const float cosTheta = fminf(dot3(scl3(d, -1.0f), normal), 1.0f);
-			const float sinTheta = sqrt_nt(1.0f - cosTheta * cosTheta);                   // 0, or at least 2^-24 in magnitude (negative: NaN, as sqrtf)
+			// 1 - c*c is 0 or at least 2^-24 in magnitude.  sqrt_pos: NaN where sqrtf gives NaN (negative) AND at 0 — either
+			// way the comparison below is false, exactly as with sqrtf's 0 (rel * 0 is 0 or NaN, never > 1)
+			const float sinTheta = sqrt_pos(1.0f - cosTheta * cosTheta);
 			bool reflect = rel * sinTheta > 1.0f;
 			if(!reflect) reflect = reflectance(cosTheta, r0) > rand_float(pt.rng);      // short-circuit draw, ray.cl:163
 			base = reflect ? reflection_dir(d, normal) : refraction_dir(d, normal, rel);
@@ -180,7 +182,7 @@ PT_DEV void candidate_key(float bHalf, float disc, int i, uint32_t &best, uint32
 	best = updf ? keyf : best;
 	return;
 #endif
-	const float num = -bHalf - sqrt_nt(disc);
+	const float num = -bHalf - sqrt_pos(disc);      // disc == 0 or inf: NaN here, and the lane is `slow` (track_tiny) or has no hit
 	const uint32_t key = __float_as_uint(num);
 	const bool upd = key < best;
 	prev = upd ? best : prev;
@@ -234,19 +236,19 @@ PT_DEV float scan_tiny_init(float a) {
 }
 
 // End of a scan: the single divide, and the checks that send a lane to the reference scan (`slow`).
-PT_DEV Hit finish_scan(float a, uint32_t best, uint32_t prev, int idx, float tiny, bool &slow) {
+PT_DEV Hit finish_scan(float a, float rinv, uint32_t best, uint32_t prev, int idx, float tiny, bool &slow) {
 	Hit h;
 	h.hit = best < KEY_NONE;
 	h.idx = idx;
 #if PT_FAST_MATH
 	h.hit = best < KEY_NONE - 1u;
-	h.t = __uint_as_float(best + 1u) * __builtin_amdgcn_rcpf(a);
+	h.t = __uint_as_float(best + 1u) * rinv;
 	slow = false;
 	return h;
 #endif
 	const float num = __uint_as_float(best);
 	const float pnum = __uint_as_float(prev);                // +inf when there is none
-	h.t = div_nt(num, a);        // exact inside the ranges checked below; outside them the lane is `slow` or has no hit
+	h.t = div_seeded(num, a, rinv);        // rinv: 1 / a to 2^-21 or better; exact inside the ranges checked below, outside them the lane is `slow` or has no hit
 	// `tiny` starts at a * 2^-56 (scan_tiny_init) and then takes the smallest |disc|: below 2^-96 means a < 2^-40, or
 	// some |disc| under sqrt_nt's domain (an exactly zero disc lands here too: rare, and exact either way)
 	slow = tiny < 0x1p-96f;
@@ -258,7 +260,7 @@ PT_DEV Hit finish_scan(float a, uint32_t best, uint32_t prev, int idx, float tin
 template <typename Tab>
 PT_DEV Hit finish_hit(const Tab geom, int n, f3 o, f3 d, float a, uint32_t best, uint32_t prev, int idx, float tiny) {
 	bool slow;
-	Hit h = finish_scan(a, best, prev, idx, tiny, slow);
+	Hit h = finish_scan(a, __builtin_amdgcn_rcpf(a), best, prev, idx, tiny, slow);
 	if(__builtin_expect(slow, 0)) h = closest_hit_reference(geom, n, o, d, a);
 	return h;
 }
@@ -331,13 +333,13 @@ PT_DEV bool wave_can_hit(float disc, float bHalf) {
 	return __builtin_amdgcn_ballot_w64(m >= 0.0f) != 0;
 }
 
-// Returns Hit.idx = LDS address of the winner's record.  `a` may be wrong when dot(d, d) < 2^-96 (the caller uses
-// the unguarded sqrt_nt); it is then below 2^-40, scan_tiny_init() starts the small-|disc| tracker below 2^-96,
-// finish_scan() asks for the reference scan, and that gets the exact value.
+// Returns Hit.idx = LDS address of the winner's record.  `a` may be wrong when dot(d, d) is 0, inf or below 2^-96 (the
+// caller uses the unguarded sqrt_pos_y); it is then NaN, inf or below 2^-40: scan_tiny_init() starts the small-|disc|
+// tracker below 2^-96 or finish_scan()'s a <= 2^40 test fails, the reference scan is asked for, and that gets the exact value.
 // `skipMask` bit t: trio t holds a sphere much smaller than the largest of the table (set by the host); such a sphere
 // is rarely a candidate for any of the 64 rays of a wave, and its sqrt/select part is entered only if it is.
 template <bool SKIP>
-PT_DEV Hit closest_hit_lds(uint32_t base, int n, unsigned skipMask, f3 o, f3 d, float a) {
+PT_DEV Hit closest_hit_lds(uint32_t base, int n, unsigned skipMask, f3 o, f3 d, float a, float ya) {
 	uint32_t best = KEY_NONE, prev = KEY_NONE;
 	float tiny = scan_tiny_init(a);
 	int idx = 0;
@@ -365,7 +367,7 @@ PT_DEV Hit closest_hit_lds(uint32_t base, int n, unsigned skipMask, f3 o, f3 d, 
 	}
 	for(; i < n; i++, addr += PT_REC_BYTES) test_sphere(lds_f4(addr), (int)addr, o, d, a, best, prev, idx, tiny);
 	bool slow;
-	Hit h = finish_scan(a, best, prev, idx, tiny, slow);
+	Hit h = finish_scan(a, ya * ya, best, prev, idx, tiny, slow);      // ya = v_rsq_f32(dot(d, d)): ya^2 seeds 1 / a (div_by_a)
 	if(__builtin_expect(slow, 0)) {
 		const float ln = len3(d);
 		const LdsGeom tab = {base};
@@ -427,9 +429,10 @@ __global__ __launch_bounds__(256) void pt_render_lds_kernel(float4 *__restrict__
 				start_sample(pt, p, id, origin, seedmul[k]);
 				for(int j = 0; j < p.maxDepth; j++) {                                    // ray.cl:96
 					if(COUNT) myBounces++;
-					const float ln = sqrt_nt(dot3(pt.d, pt.d));                          // see closest_hit_lds()
+					float ya;
+					const float ln = sqrt_pos_y(dot3(pt.d, pt.d), ya);                   // see closest_hit_lds()
 					const float a = ln * ln;                                             // ray.cl:73 pow(length(d),2)
-					const Hit h = closest_hit_lds<SKIP>(ldsBase, p.n, p.trioSkipMask, pt.o, pt.d, a);
+					const Hit h = closest_hit_lds<SKIP>(ldsBase, p.n, p.trioSkipMask, pt.o, pt.d, a, ya);
 					if(!h.hit) { color = mul3(pt.mask, mk3(p.bgx, p.bgy, p.bgz)); break; }   // ray.cl:112-115
 					const uint32_t rec = (uint32_t)h.idx;
 					if(shade_hit(pt, h.t, lds_f4(rec), lds_f4(rec + 16), lds_f4(rec + 32), color)) break;
@@ -672,7 +675,7 @@ __global__ __launch_bounds__(64) void pt_render_stream_kernel(float4 *__restrict
 				if(nchunks > 1) __syncthreads();
 			}
 			bool slow = false;
-			if(tracing) h = finish_scan(a, best, prev, idx, tiny, slow);
+			if(tracing) h = finish_scan(a, __builtin_amdgcn_rcpf(a), best, prev, idx, tiny, slow);
 			coop = __builtin_amdgcn_ballot_w64(slow);
 		}
 		// sphere-parallel: the wave takes the remaining rays one at a time, with the reference's arithmetic

@@ -71,15 +71,29 @@ def test_divide_sqrt_correctly_rounded(ctx, oracle):
 
 
 def test_short_sqrt_is_sqrtf_on_every_float(ctx):
-    """The kernels' short correctly-rounded sqrt (pt_device.h sqrt_nt / sqrt_cr) against the compiler's
-    correctly rounded sqrtf on ALL 2^32 bit patterns, on the device (sqrtf itself is pinned against the
-    CPU in test_divide_sqrt_correctly_rounded)."""
+    """The kernels' five-instruction correctly-rounded sqrt (pt_device.h: v_rsq_f32 + one Markstein step) and its guarded
+    forms against the compiler's correctly rounded sqrtf on ALL 2^32 bit patterns, on the device (sqrtf itself is pinned
+    against the CPU in test_divide_sqrt_correctly_rounded): sqrt_cr everywhere, sqrt_z on +-0 / |x| >= 2^-96 / inf / NaN,
+    sqrt_pos on 2^-96 <= x < inf and the negatives, sqrt_01 on [2^-96, 1] and +-0."""
     n = 1 << 16
     a = (np.arange(n, dtype=np.uint64) << np.uint64(16))
     b = np.full(n, 1 << 16, np.uint64)
     ou, _ = ctx.selftest(4, a=a, b=b)
-    assert int((ou & np.uint64(0xFFFFFFFF)).sum()) == 0, "sqrt_cr != sqrtf somewhere"
-    assert int((ou >> np.uint64(32)).sum()) == 0, "sqrt_nt != sqrtf inside its domain"
+    m = np.uint64((1 << 21) - 1)
+    assert int((ou & m).sum()) == 0, "sqrt_cr != sqrtf somewhere"
+    assert int(((ou >> np.uint64(21)) & m).sum()) == 0, "sqrt_z != sqrtf inside its domain"
+    assert int(((ou >> np.uint64(42)) & m).sum()) == 0, "sqrt_pos / sqrt_01 != sqrtf inside their domains"
+
+
+def test_normalize_reciprocal_length_on_every_float(ctx):
+    """normalize()'s 1 / length(v) from x = dot(v, v) (pt_device.h inv_len: ONE v_rsq_f32 serves the root and seeds the
+    reciprocal of the rounded root) == 1.0f / sqrtf(x) on all 2^32 patterns of x (pt_selftest op 11)."""
+    n = 1 << 16
+    a = (np.arange(n, dtype=np.uint64) << np.uint64(16))
+    b = np.full(n, 1 << 16, np.uint64)
+    ou, _ = ctx.selftest(11, a=a, b=b)
+    bad = np.nonzero(ou)[0]
+    assert len(bad) == 0, "inv_len(x) != 1/sqrtf(x) in %d chunks, first at bits 0x%08x" % (len(bad), int(bad[0]) << 16)
 
 
 def test_short_reciprocal_is_the_divide_on_every_float(ctx):
@@ -103,6 +117,10 @@ def test_short_divide_is_the_divide_on_its_range(ctx):
     ou, _ = ctx.selftest(7, a=a, b=b)
     assert int((ou >> np.uint64(32)).sum()) == n * per, "op 7 compared %d pairs, expected %d" % (int((ou >> np.uint64(32)).sum()), n * per)
     assert int((ou & np.uint64(0xFFFFFFFF)).sum()) == 0, "div_nt != / on %d pairs" % int((ou & np.uint64(0xFFFFFFFF)).sum())
+    # the lock-step kernel's form of the same divide: den = a = RN(RN(sqrt(x))^2), reciprocal seeded with v_rsq_f32(x)^2 (op 10)
+    ou, _ = ctx.selftest(10, a=a, b=b)
+    assert int((ou >> np.uint64(32)).sum()) == n * per
+    assert int((ou & np.uint64(0xFFFFFFFF)).sum()) == 0, "div_by_a != / on %d pairs" % int((ou & np.uint64(0xFFFFFFFF)).sum())
     ou, _ = ctx.selftest(8, a=a[:256], b=b[:256])
     assert int((ou >> np.uint64(32)).sum()) == 256 * per
     bad = int((ou & np.uint64(0xFFFFFFFF)).sum())
