@@ -601,6 +601,7 @@ static int launch_frames(pt_ctx *c, const pt_render_args *a, float4 *img, hipStr
 	memset(&la.grid, 0, sizeof la.grid);
 	if(useGrid) { la.grid = c->grid; la.kernel = PT_K_GRID; }
 	la.ldsBytes = la.kernel == PT_K_LDS ? pt_strict::lds_table_bytes(c->nSpheres) : 0;
+	la.genericScan = getenv("PT_GENERIC_SCAN") != NULL;
 	// streaming kernel: persistent one-wave blocks, at most 32 per CU; surplus pixels come through the queue
 	const long long swaves = (lp + 63) / 64;
 	la.gridStream = (unsigned)(swaves < 256 * 32 ? swaves : 256 * 32);

@@ -64,6 +64,7 @@ struct LaunchArgs {
 	unsigned gridPixels;          // blocks of 256 threads over localPixels << logS
 	unsigned gridStream;          // one-wave blocks of the streaming kernel
 	size_t ldsBytes;
+	bool genericScan;             // debugging aid (PT_GENERIC_SCAN): the scan loop even where an unrolled instance exists
 	GridTables grid;              // PT_K_GRID only
 };
 enum { PT_K_LDS = 0, PT_K_STREAM = 1, PT_K_GRID = 3 };

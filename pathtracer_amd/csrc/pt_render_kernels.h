@@ -154,9 +154,16 @@ constexpr uint32_t KEY_NONE = 0x7f800000u;   // bits(+inf)
 // src/cl/ray.cl:72-76 — bHalf and the discriminant, in the reference's operation order
 PT_DEV void sphere_disc(const float4 g, f3 o, f3 d, float a, float &bHalf, float &disc) {
 	const f3 oc = sub3(o, mk3(g.x, g.y, g.z));
+#if PT_FAST_MATH
+	// relaxed build: eight FMAs and three subtractions per test, -r^2 folded into the first product of c
+	bHalf = __builtin_fmaf(oc.z, d.z, __builtin_fmaf(oc.y, d.y, oc.x * d.x));
+	const float c = __builtin_fmaf(oc.z, oc.z, __builtin_fmaf(oc.y, oc.y, __builtin_fmaf(oc.x, oc.x, -g.w)));
+	disc = __builtin_fmaf(-a, c, bHalf * bHalf);
+#else
 	bHalf = dot3(oc, d);
 	const float c = oc.x * oc.x + oc.y * oc.y + oc.z * oc.z - g.w;
 	disc = bHalf * bHalf - a * c;
+#endif
 }
 
 // smallest |disc| seen, as one v_min_f32 with the |x| source modifier (fminf(fabsf()) costs two extra
@@ -338,32 +345,51 @@ PT_DEV bool wave_can_hit(float disc, float bHalf) {
 // tracker below 2^-96 or finish_scan()'s a <= 2^40 test fails, the reference scan is asked for, and that gets the exact value.
 // `skipMask` bit t: trio t holds a sphere much smaller than the largest of the table (set by the host); such a sphere
 // is rarely a candidate for any of the 64 rays of a wave, and its sqrt/select part is entered only if it is.
+// One trio of the lock-step scan (closest_hit_lds)
 template <bool SKIP>
+PT_DEV void scan_trio(uint32_t addr, bool skipBit, f3 o, f3 d, float a, uint32_t &best, uint32_t &prev, int &idx, float &tiny) {
+	const float4 g0 = lds_f4(addr), g1 = lds_f4(addr + PT_REC_BYTES), g2 = lds_f4(addr + 2 * PT_REC_BYTES);
+	const int4 ii = lds_i4(addr + 3 * PT_REC_BYTES);
+	float b0, b1, b2, d0, d1, d2;
+	sphere_disc(g0, o, d, a, b0, d0);
+	sphere_disc(g1, o, d, a, b1, d1);
+	sphere_disc(g2, o, d, a, b2, d2);
+	if(SKIP && skipBit) {
+		if(wave_can_hit(d0, b0)) candidate_update(b0, d0, ii.x, best, prev, idx, tiny);
+		if(wave_can_hit(d1, b1)) candidate_update(b1, d1, ii.y, best, prev, idx, tiny);
+		if(wave_can_hit(d2, b2)) candidate_update(b2, d2, ii.z, best, prev, idx, tiny);
+	} else {
+		track_tiny2(d0, d1, tiny);
+		track_tiny(d2, tiny);
+		candidate_key(b0, d0, ii.x, best, prev, idx);
+		candidate_key(b1, d1, ii.y, best, prev, idx);
+		candidate_key(b2, d2, ii.z, best, prev, idx);
+	}
+}
+
+// NT > 0: the table has exactly NT trios and no remainder (n == 3 * NT) and the small-sphere mask is the compile-time
+// constant MASK: the scan is straight-line code, which spares the loop-carried register copies (4 per trio) and the
+// merges of the two forms of a trio, and lets the compiler keep the first trio in registers across bounces (the
+// reference's nine-sphere scene: 165.9 -> 162 ms).  NT == 0: any table; MASK < 0 is then -1 (small-sphere tests by the
+// run-time mask) or -2 (none).
+template <int NT, int MASK>
 PT_DEV Hit closest_hit_lds(uint32_t base, int n, unsigned skipMask, f3 o, f3 d, float a, float ya) {
 	uint32_t best = KEY_NONE, prev = KEY_NONE;
 	float tiny = scan_tiny_init(a);
 	int idx = 0;
 	uint32_t addr = base;
 	int i = 0;
-	for(; i + 3 <= n; i += 3, addr += PT_TRIO_BYTES) {
-		const float4 g0 = lds_f4(addr), g1 = lds_f4(addr + PT_REC_BYTES), g2 = lds_f4(addr + 2 * PT_REC_BYTES);
-		const int4 ii = lds_i4(addr + 3 * PT_REC_BYTES);
-		float b0, b1, b2, d0, d1, d2;
-		sphere_disc(g0, o, d, a, b0, d0);
-		sphere_disc(g1, o, d, a, b1, d1);
-		sphere_disc(g2, o, d, a, b2, d2);
-		if(SKIP && (skipMask & 1u)) {
-			if(wave_can_hit(d0, b0)) candidate_update(b0, d0, ii.x, best, prev, idx, tiny);
-			if(wave_can_hit(d1, b1)) candidate_update(b1, d1, ii.y, best, prev, idx, tiny);
-			if(wave_can_hit(d2, b2)) candidate_update(b2, d2, ii.z, best, prev, idx, tiny);
-		} else {
-			track_tiny2(d0, d1, tiny);
-			track_tiny(d2, tiny);
-			candidate_key(b0, d0, ii.x, best, prev, idx);
-			candidate_key(b1, d1, ii.y, best, prev, idx);
-			candidate_key(b2, d2, ii.z, best, prev, idx);
+	constexpr bool SKIP = NT > 0 ? MASK != 0 : MASK == -1;
+	if(NT > 0) {
+		skipMask = (unsigned)MASK;      // a compile-time constant from here on
+#pragma unroll
+		for(int t = 0; t < NT; t++) scan_trio<SKIP>(base + PT_TRIO_BYTES * t, SKIP && ((skipMask >> t) & 1u), o, d, a, best, prev, idx, tiny);
+		i = n;
+	} else {
+		for(; i + 3 <= n; i += 3, addr += PT_TRIO_BYTES) {
+			scan_trio<SKIP>(addr, SKIP && (skipMask & 1u), o, d, a, best, prev, idx, tiny);
+			if(SKIP) skipMask >>= 1;
 		}
-		if(SKIP) skipMask >>= 1;
 	}
 	for(; i < n; i++, addr += PT_REC_BYTES) test_sphere(lds_f4(addr), (int)addr, o, d, a, best, prev, idx, tiny);
 	bool slow;
@@ -383,8 +409,13 @@ PT_DEV Hit closest_hit_lds(uint32_t base, int n, unsigned skipMask, f3 o, f3 d, 
 // wave-uniform (geometry) or per-lane (material of the winning sphere) ds_reads, so the
 // arithmetic runs on VGPR operands at full VALU rate.
 // ---------------------------------------------------------------------------------------
-template <bool COUNT, bool SKIP>
-__global__ __launch_bounds__(256) void pt_render_lds_kernel(float4 *__restrict__ image, const KParams p, const SceneTables sc,
+#ifndef PT_LDS_WAVES
+#define PT_LDS_BOUNDS __launch_bounds__(256)
+#else
+#define PT_LDS_BOUNDS __launch_bounds__(256, PT_LDS_WAVES)
+#endif
+template <bool COUNT, int NT, int MASK>
+__global__ PT_LDS_BOUNDS void pt_render_lds_kernel(float4 *__restrict__ image, const KParams p, const SceneTables sc,
                                                              const uint64_t *__restrict__ seedmul,
                                                              unsigned long long *__restrict__ bounceCounter) {
 	extern __shared__ float4 lds[];
@@ -429,10 +460,15 @@ __global__ __launch_bounds__(256) void pt_render_lds_kernel(float4 *__restrict__
 				start_sample(pt, p, id, origin, seedmul[k]);
 				for(int j = 0; j < p.maxDepth; j++) {                                    // ray.cl:96
 					if(COUNT) myBounces++;
+#if PT_FAST_MATH
+					// relaxed build: pow(length(d), 2) as dot(d, d); closest_hit_lds() squares its last argument for 1 / a
+					const float a = dot3(pt.d, pt.d), ya = __builtin_amdgcn_rsqf(a);
+#else
 					float ya;
 					const float ln = sqrt_pos_y(dot3(pt.d, pt.d), ya);                   // see closest_hit_lds()
 					const float a = ln * ln;                                             // ray.cl:73 pow(length(d),2)
-					const Hit h = closest_hit_lds<SKIP>(ldsBase, p.n, p.trioSkipMask, pt.o, pt.d, a, ya);
+#endif
+					const Hit h = closest_hit_lds<NT, MASK>(ldsBase, p.n, p.trioSkipMask, pt.o, pt.d, a, ya);
 					if(!h.hit) { color = mul3(pt.mask, mk3(p.bgx, p.bgy, p.bgz)); break; }   // ray.cl:112-115
 					const uint32_t rec = (uint32_t)h.idx;
 					if(shade_hit(pt, h.t, lds_f4(rec), lds_f4(rec + 16), lds_f4(rec + 32), color)) break;
@@ -719,10 +755,18 @@ __global__ __launch_bounds__(64) void pt_render_stream_kernel(float4 *__restrict
 void launch_render(const LaunchArgs &la) {
 	const dim3 block(256), grid(la.gridPixels), sgrid(la.gridStream);
 	if(la.kernel == PT_K_LDS) {
-		// four instances: with/without the in-kernel bounce count, with/without the small-sphere tests in the scan
-		void (*k)(float4 *, const KParams, const SceneTables, const uint64_t *, unsigned long long *) =
-			la.count ? (la.p.trioSkipMask ? pt_render_lds_kernel<true, true> : pt_render_lds_kernel<true, false>)
-			         : (la.p.trioSkipMask ? pt_render_lds_kernel<false, true> : pt_render_lds_kernel<false, false>);
+		// instances: with/without the in-kernel bounce count; the generic scan loop with/without the small-sphere tests;
+		// and, for a table of exactly nine spheres (the reference's scene), the unrolled scan for each of the 8 masks
+		typedef void (*kern_t)(float4 *, const KParams, const SceneTables, const uint64_t *, unsigned long long *);
+		static const kern_t nine[2][8] = {
+			{pt_render_lds_kernel<false, 3, 0>, pt_render_lds_kernel<false, 3, 1>, pt_render_lds_kernel<false, 3, 2>, pt_render_lds_kernel<false, 3, 3>,
+			 pt_render_lds_kernel<false, 3, 4>, pt_render_lds_kernel<false, 3, 5>, pt_render_lds_kernel<false, 3, 6>, pt_render_lds_kernel<false, 3, 7>},
+			{pt_render_lds_kernel<true, 3, 0>, pt_render_lds_kernel<true, 3, 1>, pt_render_lds_kernel<true, 3, 2>, pt_render_lds_kernel<true, 3, 3>,
+			 pt_render_lds_kernel<true, 3, 4>, pt_render_lds_kernel<true, 3, 5>, pt_render_lds_kernel<true, 3, 6>, pt_render_lds_kernel<true, 3, 7>}};
+		kern_t k;
+		if(la.p.n == 9 && !la.genericScan) k = nine[la.count ? 1 : 0][la.p.trioSkipMask & 7u];
+		else if(la.p.trioSkipMask) k = la.count ? pt_render_lds_kernel<true, 0, -1> : pt_render_lds_kernel<false, 0, -1>;
+		else k = la.count ? pt_render_lds_kernel<true, 0, -2> : pt_render_lds_kernel<false, 0, -2>;
 		hipLaunchKernelGGL(k, grid, block, la.ldsBytes, la.stream, la.image, la.p, la.sc, la.seedmul, la.bounceCounter);
 	} else {
 		const bool g = la.kernel == PT_K_GRID;

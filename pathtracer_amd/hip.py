@@ -10,7 +10,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpt_hip.so")
+# PT_HIP_LIB: debugging aid for A/B timing of kernel variants (tools/ab_build.sh): another build of the same library
+LIB_PATH = os.environ.get("PT_HIP_LIB") or os.path.join(_HERE, "libpt_hip.so")
 
 PT_SPHERE_FLOATS = 12
 

@@ -391,3 +391,26 @@ def test_small_sphere_tests_in_the_scan_change_nothing(ctx, name):
         os.environ.pop("PT_NO_TRIO_SKIP", None)
         os.environ.pop("PT_KERNEL", None)
     assert np.array_equal(bits(img[..., :3]), bits(g["strict"])), mismatch_report(img[..., :3], g["strict"])
+
+
+@pytest.mark.parametrize("name", ["frame0_64x36", "frame77_96x54", "frame211_80x45", "depth1_32x32", "frame0_scale_m45_48x27", "frame0_scale_p57_48x27"])
+@pytest.mark.parametrize("noskip", [False, True])
+def test_scan_loop_and_unrolled_scan_agree_on_nine_sphere_tables(ctx, name, noskip):
+    """Tables of exactly nine spheres (the reference's scene) run an unrolled instance of the lock-step scan, one per
+    small-sphere mask; PT_GENERIC_SCAN forces the scan loop every other table size uses.  Both must give the strict
+    reference fixture (the default path is checked by test_render_matches_oracle_and_reference_fixture)."""
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    W, H, depth, spp = (int(x) for x in g["size"])
+    sc = {"spheres": g["spheres"], "bg": g["bg"], "cam": g["cam"]}
+    assert sc["spheres"].shape[0] == 9
+    try:
+        os.environ["PT_GENERIC_SCAN"] = "1"
+        if noskip:
+            os.environ["PT_NO_TRIO_SKIP"] = "1"
+        img, bc = hip.render_scene(ctx, sc, W, H, depth, g["seeds"], count_bounces=True)
+        img2 = hip.render_scene(ctx, sc, W, H, depth, g["seeds"])
+    finally:
+        os.environ.pop("PT_GENERIC_SCAN", None)
+        os.environ.pop("PT_NO_TRIO_SKIP", None)
+    assert np.array_equal(bits(img[..., :3]), bits(g["strict"])), mismatch_report(img[..., :3], g["strict"])
+    assert np.array_equal(bits(img2[..., :3]), bits(g["strict"]))
