@@ -39,13 +39,27 @@ def flops_per_sample(bounces_per_sample, n_spheres, mbar=MBAR_DEFAULT_SCENE):
     return bounces_per_sample * (18.0 * n_spheres + 34.0 + mbar) + 60.0
 
 
+def _cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(scene, seeds):
-    """The reference kernel (x86 build, oracle/_ref) or, where that is absent, the oracle port, timed
-    on the host cores on a bounded sample of the same workload: every pixel of the 1080p image at the
+    """The reference kernel (x86 build, oracle/_ref — built in the build container from the reference's sources and
+    shipped as a .so like our own libraries) or, where that is absent, the oracle port, timed on the
+    host cores this job may use, on a bounded sample of the same workload: every pixel of the 1080p image at the
     first 4 of its 256 samples (8.3 M samples)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib
-    cores = min(16, os.cpu_count() or 1)
+    host_cpus = os.cpu_count() or 1
+    # the GPU box exports the job's CPU share (16 per GPU) as OMP_NUM_THREADS; os.cpu_count() is the whole machine
+    share = int(os.environ.get("OMP_NUM_THREADS", "0") or 0)
+    cores = min(host_cpus, share) if share > 0 else host_cpus
     spp = 4
     if oracle_lib.have_ref("fast"):
         lib, kind = oracle_lib.load_ref("fast"), "reference"
@@ -55,8 +69,44 @@ def cpu_baseline(scene, seeds):
     lib.render(scene, WIDTH, HEIGHT, DEPTH, seeds[:spp], nthreads=cores)
     dt = time.perf_counter() - t0
     return {"value": WIDTH * HEIGHT * spp / dt / 1e6, "unit": "Msamples/s", "cores": cores, "kind": kind,
-            "sample": "all %dx%d pixels at the first %d of %d spp (%.1f M samples, %.1f s)" %
-                      (WIDTH, HEIGHT, spp, SPP, WIDTH * HEIGHT * spp / 1e6, dt)}
+            "host_cpus": host_cpus, "cpu_model": _cpu_model(),
+            "sample": "all %dx%d pixels at the first %d of %d spp (%.1f M samples, %.1f s) on %d threads (the job's CPU share; "
+                      "the machine has %d)" % (WIDTH, HEIGHT, spp, SPP, WIDTH * HEIGHT * spp / 1e6, dt, cores, host_cpus)}
+
+
+VERIFY_ROWS = (0, 1, 269, 540, 777, 1079)
+
+
+def verify_frame(frame_rows, scene, seeds, rows):
+    """Rows of the frame the timed loop produced against the CPU oracle at the FULL sample count, bit for bit.
+    Checker only: runs after the timed region.  Raises SystemExit on a mismatch."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+    oracle = oracle_lib.load_oracle()
+    threads = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16") or 16))
+    for r, got in zip(rows, frame_rows):
+        want = oracle.render(scene, WIDTH, HEIGHT, DEPTH, seeds, id_begin=r * WIDTH, id_end=(r + 1) * WIDTH, nthreads=threads)[r, :, :3]
+        if not np.array_equal(np.ascontiguousarray(got[:, :3]).view(np.uint32), np.ascontiguousarray(want).view(np.uint32)):
+            bad = int((np.ascontiguousarray(got[:, :3]).view(np.uint32) != np.ascontiguousarray(want).view(np.uint32)).any(axis=1).sum())
+            raise SystemExit("bench.py: row %d of the benchmarked frame differs from the oracle in %d pixels (max abs %.3g)"
+                             % (r, bad, float(np.abs(got[:, :3] - want).max())))
+    return len(rows)
+
+
+def measured_traffic():
+    """HBM bytes per launch of the dominant kernel from the newest PMC summary of it in profiles/ (WRITE_SIZE + FETCH_SIZE,
+    KiB per dispatch as rocprofv3 reports them; the table is read from LDS and the reads are not wide streaming loads, so no
+    x2 correction applies to the 0.05-0.1 MB that are fetched).  Returns (bytes, file) or (None, None)."""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_lds_strict*.md")))
+    for f in reversed(files):
+        text = open(f).read()
+        w = re.search(r"\|\s*WRITE_SIZE\s*\|\s*([0-9.e+]+)", text)
+        r = re.search(r"\|\s*FETCH_SIZE\s*\|\s*([0-9.e+]+)", text)
+        if w and r:
+            return (float(w.group(1)) + float(r.group(1))) * 1024.0, os.path.relpath(f, ROOT)
+    return None, None
 
 
 def main():
@@ -65,6 +115,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-verify", action="store_true", help="skip the oracle check of the benchmarked frame (about 3 s of CPU)")
     ap.add_argument("--no-fast-math", action="store_true", help="skip the extra, untimed measurement of the relaxed-float build")
     ap.add_argument("--force-dist", action="store_true",
                     help="debug: run the multi-rank code path (process group, zero-fill, RCCL reduce, barrier) even with one rank")
@@ -159,6 +210,14 @@ def main():
     assert len(kern_times) == args.steps, (len(kern_times), args.steps)
     kern_ms = float(np.mean(kern_times))
 
+    # outside the timed region: rows of the frame the last timed step left (rank 0 holds the whole image, after the
+    # reduce when N > 1) against the CPU oracle at the full sample count, bit for bit
+    verified = 0
+    if rank == 0 and not args.no_verify:
+        torch.cuda.synchronize()
+        rows = [frame[r].cpu().numpy() for r in VERIFY_ROWS]
+        verified = verify_frame(rows, scene, seeds, VERIFY_ROWS)
+
     # untimed extra (rank-local, N=1 only): the opt-in relaxed-float build of the same kernel, for the roofline
     # discussion — NOT the reported value, its image is within tolerance of the oracle, not bit-identical
     fast_ms = None
@@ -179,6 +238,7 @@ def main():
         total_bounces, kern_ms_max = float(my_bounces), kern_ms
 
     if rank == 0:
+        traffic, traffic_file = measured_traffic() if world == 1 else (None, None)
         samples = WIDTH * HEIGHT * spp
         bps = total_bounces / samples
         fps = flops_per_sample(bps, n_spheres)
@@ -199,13 +259,17 @@ def main():
             "config": {"workload": "main.lua frame-0 scene 1920x1080 %d spp depth 50 (BASELINE configs[1])" % spp,
                        "spheres": n_spheres, "seeds": "glibc rand() stream, first %d values" % spp,
                        "partition": "1 GPU" if world == 1 else "%d-row bands round-robin over %d ranks + RCCL reduce" % (BAND_ROWS, world),
-                       "bounces_per_sample": round(bps, 3)},
+                       "bounces_per_sample": round(bps, 3),
+                       "verified_rows": verified,
+                       "verified": ("rows %s of the last timed frame bit-identical to the CPU oracle at %d spp" % (list(VERIFY_ROWS), spp))
+                                   if verified else "skipped"},
             "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_VALU_TFLOPS,
-                         # HBM bytes per launch from the PMC passes in profiles/ (WRITE_SIZE = the 16 B/pixel
-                         # accumulator written once, FETCH_SIZE ~0.1 MB): traffic == algorithmic bytes, and at
-                         # ~0.15 TB/s it is two orders of magnitude under the HBM roof — this path is VALU-bound
-                         "traffic": 16.0 * WIDTH * HEIGHT / max(world, 1) + 2 * 64e3 if world >= 1 else None,
+                         # HBM bytes per launch: the counter reading of the newest PMC summary of this kernel in profiles/
+                         # (same frame: the accumulator write does not depend on spp), not a formula; the algorithmic
+                         # bytes (16 B/pixel written once + the tables and seeds read) are given beside it
+                         "traffic": traffic, "traffic_source": traffic_file,
+                         "traffic_model": 16.0 * WIDTH * HEIGHT / max(world, 1) + 432 + 8 * spp,
                          "kernel": "pt_render_lds_kernel", "kernel_ms": kern_ms,
                          "flops_per_sample": round(fps, 1),
                          "note": "FP32 vector roofline (no dense contraction on this path, SURVEY.md §8d); "

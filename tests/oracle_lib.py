@@ -11,7 +11,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_SO = os.path.join(ROOT, "oracle", "libpt_oracle.so")
-REF_SO = {k: os.path.join(ROOT, "oracle", "_ref", "libptref_%s.so" % k) for k in ("strict", "fast")}
+REF_SO = {k: os.path.join(ROOT, "oracle", "_ref", "libptref_%s.so" % k) for k in ("strict", "fast", "env1", "env2", "env3")}
 
 _f = C.POINTER(C.c_float)
 _u64p = C.POINTER(C.c_uint64)

@@ -1,15 +1,18 @@
 """The opt-in relaxed build (pt_render_args.fast_math / PT_MATH=fast): FMA contraction and the 1-ulp hardware sqrt
 and reciprocal — the freedoms of the reference's own build options (src/c/renderer.c:13).  Same integer RNG stream;
 the float image is NOT bit-identical: a perturbation of an ulp flips a hit/miss or reflect/refract decision about
-once per 3e5 bounces, and from there the path is a different, equally valid one.  Stated tolerance, per fixture
-(8-16 spp, where one flipped sample moves a pixel by up to 10/spp): >= 98 % of the pixels within 1e-4 of the strict
-reference image, every other pixel finite, bounce count within 0.5 %, image mean within 2 %.  Scenes without a
-decision near the perturbation (single-material micro scenes) stay within 2e-6 everywhere."""
+once per 3e5 bounces, and from there the path is a different, equally valid one.  Stated tolerance (tests/envelope.py,
+DESIGN.md §2 — the one legal builds of the REFERENCE meet among themselves): at most 2 + 6e-6 * (bounce iterations x
+spheres) pixels farther than 1e-4 from the strict reference image, every pixel finite, bounce count within 0.5 %, image mean within 2 % (these
+fixtures are a few thousand pixels: one flipped sample moves the mean visibly).  Scenes without a decision near the
+perturbation (single-material micro scenes) stay within 2e-6 everywhere.  The envelope cases, at sizes where shares
+of pixels and the PSNR of the 8-bit image are meaningful, are in tests/test_gpu_envelope.py."""
 import os
 
 import numpy as np
 import pytest
 
+import envelope
 from cases import CASES
 from pathtracer_amd import hip
 
@@ -29,7 +32,8 @@ def test_fast_math_within_stated_tolerance(ctx, name):
     rgb = img[..., :3]
     assert np.isfinite(rgb).all() and rgb.min() >= 0
     d = np.abs(rgb - g["strict"]).max(axis=2)
-    assert (d <= 1e-4).mean() >= 0.98, "only %.4f of the pixels within 1e-4" % (d <= 1e-4).mean()
+    budget = envelope.off_pixel_budget(bs, sc["spheres"].shape[0])
+    assert int((d > 1e-4).sum()) <= budget, "%d pixels farther than 1e-4 (budget %d)" % (int((d > 1e-4).sum()), budget)
     assert abs(bc - bs) <= max(16, 0.005 * bs)
     m_fast, m_ref = float(rgb.mean()), float(g["strict"].mean())
     assert abs(m_fast - m_ref) <= 0.02 * max(m_ref, 1e-3) + 1e-6

@@ -7,6 +7,7 @@ import os
 import numpy as np
 import pytest
 
+import envelope
 from cases import CASES
 from pathtracer_amd import hip, scenes
 from pathtracer_amd import seeds as seedmod
@@ -178,7 +179,7 @@ def test_render_matches_oracle_and_reference_fixture(ctx, oracle, name):
     # against the reference built with its own fast-math flags: the tolerance two builds of the reference meet
     d = np.abs(img[..., :3] - g["fast"]).max(axis=2)
     if name.startswith("dense"):
-        assert (d <= 1e-4).mean() >= 0.995
+        assert envelope.off_pixels(img[..., :3], g["fast"]) <= envelope.off_pixel_budget(bounces, sc["spheres"].shape[0])      # flip budget, tests/envelope.py
     else:
         assert d.max() <= 1e-5
     # the non-counting kernel variant gives the same image
@@ -279,6 +280,39 @@ def test_full_size_properties(ctx, oracle):
     assert np.array_equal(bits(ctx.image_read()[..., :3]), bits(img[..., :3]))
     u8 = ctx.image_read_u8()
     assert np.array_equal(u8[540], oracle.postprocess(img[540]))
+
+
+def test_headline_frame_at_its_full_sample_count(ctx, oracle):
+    """BASELINE config 2 exactly as bench.py times it: 1920x1080, 256 spp, depth 50, the first 256 glibc seeds —
+    64 rounds of the four-lanes-per-pixel group accumulation.  Sampled rows against the oracle at the full 256 spp,
+    bit for bit; the 8-bit image of those rows; the bounce count the roofline figure is computed from."""
+    sc = scenes.main_lua_frame(0)
+    W, H, spp = 1920, 1080, 256
+    s = seedmod.glibc_rand_stream(spp)
+    img, bounces = hip.render_scene(ctx, sc, W, H, 50, s, count_bounces=True)
+    u8 = ctx.image_read_u8()
+    for r in (0, 333, 540, 1079):
+        want = oracle.render(sc, W, H, 50, s, id_begin=r * W, id_end=(r + 1) * W, nthreads=16)
+        assert np.array_equal(bits(img[r, :, :3]), bits(want[r, :, :3])), "row %d: %s" % (r, mismatch_report(img[r, :, :3], want[r, :, :3]))
+        assert np.array_equal(u8[r], oracle.postprocess(want[r]))
+    assert abs(bounces / (W * H * spp) - 47.47) < 0.05
+    # the non-counting kernel (the one that is timed) gives the same frame
+    img2 = hip.render_scene(ctx, sc, W, H, 50, s)
+    assert np.array_equal(bits(img2[..., :3]), bits(img[..., :3]))
+
+
+def test_config3_hundred_thousand_spheres_at_1080p(ctx, oracle):
+    """BASELINE config 3 at its largest table AND its full image size: 10^5 spheres, 1920x1080, 1 spp.  The oracle needs
+    ~5 ms per path here, so segments of pixels are compared (bit for bit), spread over the image."""
+    sc = scenes.dense_random(100000)
+    W, H = 1920, 1080
+    s = seedmod.glibc_rand_stream(1)
+    img, bc = hip.render_scene(ctx, sc, W, H, 50, s, count_bounces=True)
+    assert not np.isnan(img).any() and 3.0 < bc / (W * H) < 8.0
+    flat = img.reshape(-1, 4)
+    for start in (0, 517 * W + 900, 540 * W + 960, 1079 * W + 1792):
+        want = oracle.render(sc, W, H, 50, s, id_begin=start, id_end=start + 128, nthreads=16).reshape(-1, 4)
+        assert np.array_equal(bits(flat[start:start + 128, :3]), bits(want[start:start + 128, :3])), "pixels %d.." % start
 
 
 def test_streaming_kernel_composes_and_partitions(ctx, oracle):

@@ -6,6 +6,7 @@ import os
 import numpy as np
 import pytest
 
+import envelope
 import oracle_lib
 from cases import CASES
 from pathtracer_amd import seeds as seedmod
@@ -99,16 +100,47 @@ def test_oracle_matches_reference_images(oracle, name):
     for key in ("spheres", "bg", "cam"):
         assert np.array_equal(bits(fresh[key]), bits(sc[key])), key
     assert np.array_equal(g["seeds"], seedmod.glibc_rand_stream(spp))
-    img = oracle.render(sc, W, H, depth, g["seeds"])
+    img, bounces = oracle.render(sc, W, H, depth, g["seeds"], count_bounces=True)
     assert not np.isnan(img).any()
     assert np.array_equal(bits(img[..., :3]), bits(g["strict"])), "oracle != strict reference build"
     d = np.abs(img[..., :3] - g["fast"]).max(axis=2)
     if name.startswith("dense"):
-        # two builds of the REFERENCE ITSELF (with / without its fast-math flags) flip a few paths
-        # in the dense open scenes (3 of 2304 pixels on dense3000): the floor for any other build
-        assert (d <= 1e-4).mean() >= 0.995, "vs fast-math reference build: %.5f within 1e-4" % (d <= 1e-4).mean()
+        # two builds of the REFERENCE ITSELF (with / without its fast-math flags) flip a few samples in the dense open
+        # scenes (3 of 2304 pixels on dense3000): inside the flip budget of tests/envelope.py
+        assert envelope.off_pixels(img[..., :3], g["fast"]) <= envelope.off_pixel_budget(bounces, sc["spheres"].shape[0])
     else:
         assert d.max() <= 1e-5
+
+
+@pytest.mark.parametrize("name", sorted(envelope.ENVELOPE_CASES))
+def test_stated_tolerance_holds_over_the_envelope_of_legal_reference_builds(oracle, name):
+    """The float tolerance of DESIGN.md §2 is stated against an ENVELOPE: the reference kernel built with its own
+    fast-math flags and linked with four legal definitions of the OpenCL builtins (oracle/ref_shim.cpp,
+    oracle/ref_shim_variants.cpp), plus the strict build.  Here: the committed inputs are what the factories produce,
+    the oracle is the strict member bit for bit, and EVERY PAIR of members meets the stated numbers — i.e. the
+    tolerance is one that legal builds of the reference meet among themselves (and is not looser than 0.15 percentage
+    points / 1.5 dB beyond what they need)."""
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    factory, W, H, depth, spp = envelope.ENVELOPE_CASES[name]
+    assert [int(x) for x in g["size"]] == [W, H, depth, spp]
+    fresh = factory()
+    for key in ("spheres", "bg", "cam"):
+        assert np.array_equal(bits(fresh[key]), bits(g[key])), key
+    sc = {"spheres": g["spheres"], "bg": g["bg"], "cam": g["cam"]}
+    img, bounces = oracle.render(sc, W, H, depth, g["seeds"], count_bounces=True)
+    assert np.array_equal(bits(img[..., :3]), bits(g["strict"]))
+    u8 = {k: oracle.postprocess(np.concatenate([g[k], np.zeros((H, W, 1), np.float32)], axis=2)).reshape(H, W, 3)
+          for k in envelope.ENVELOPE_KINDS}
+    worst_share, worst_psnr = 1.0, float("inf")
+    for a in envelope.ENVELOPE_KINDS:
+        for b in envelope.ENVELOPE_KINDS:
+            if a != b:
+                envelope.check_against_member(name, g[a], u8[a], g[b], u8[b])
+                assert envelope.off_pixels(g[a], g[b]) <= envelope.off_pixel_budget(bounces, sc["spheres"].shape[0])
+                worst_share = min(worst_share, envelope.share_within(g[a], g[b]))
+                worst_psnr = min(worst_psnr, envelope.psnr_u8(u8[a], u8[b]))
+    tol = envelope.ENVELOPE_TOL[name]
+    assert worst_share - tol["share"] <= 0.0025 and worst_psnr - tol["psnr"] <= 1.6, (worst_share, worst_psnr)
 
 
 def test_oracle_special_cases(oracle):

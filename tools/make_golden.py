@@ -9,6 +9,8 @@ single-function known-answer vectors.  No reference source is stored.
   strict : kernel compiled without fast-math flags     -> the oracle must match bit for bit
   fast   : kernel compiled with the reference's own PROGRAM_ARGS flags
            (/root/reference/src/c/renderer.c:13)        -> the oracle must match within 1e-5
+  env1-3 : (envelope cases only, tests/envelope.py) those flags + three other legal definitions of the OpenCL builtins
+           (oracle/ref_shim_variants.cpp)               -> what the float tolerance is stated against
 """
 import os
 import sys
@@ -21,6 +23,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import oracle_lib  # noqa: E402
 from cases import CASES  # noqa: E402
+from envelope import ENVELOPE_CASES, ENVELOPE_KINDS  # noqa: E402
 from pathtracer_amd import seeds as seedmod  # noqa: E402
 
 
@@ -42,6 +45,17 @@ def main():
                             strict=a[..., :3].copy(), fast=b[..., :3].copy())
         print("%-22s %dx%d depth %d spp %d  mean %.5f  |strict-fast|max %.3g" %
               (name, W, H, depth, spp, float(a[..., :3].mean()), float(np.abs(a - b).max())))
+
+    # envelope cases: the same scene through every legal build of the reference (oracle/ref_shim_variants.cpp)
+    if not only or "envelope" in only:
+        libs = {k: oracle_lib.load_ref(k) for k in ENVELOPE_KINDS}
+        for name, (factory, W, H, depth, spp) in ENVELOPE_CASES.items():
+            sc = factory()
+            s = stream[:spp]
+            imgs = {k: libs[k].render(sc, W, H, depth, s)[..., :3].copy() for k in ENVELOPE_KINDS}
+            np.savez_compressed(os.path.join(out, name + ".npz"), spheres=sc["spheres"], bg=sc["bg"], cam=sc["cam"],
+                                seeds=s, size=np.asarray([W, H, depth, spp], np.int32), **imgs)
+            print("%-24s %dx%d depth %d spp %d  %d KB" % (name, W, H, depth, spp, os.path.getsize(os.path.join(out, name + ".npz")) // 1024))
 
     if only and "kat" not in only:
         return
