@@ -122,6 +122,18 @@ int pt_render(pt_ctx *ctx, const pt_render_args *args);
 #define PT_NOALLOC_MAX_FRAMES 4096
 int pt_render_noalloc(pt_ctx *ctx, const pt_render_args *args);
 
+/* Multi-GPU combine, for one process driving several GPUs (pathtracer_amd/csrc/renderer.c with PT_NUM_GPUS > 1).
+ * NO COUNTERPART IN THE REFERENCE (single device, src/c/renderer.c:72); SURVEY.md §8e.  ctxs[i] is rank i of world n:
+ * each has rendered its own row bands (pt_render with rank = i, world = n, band_rows) into its context accumulator
+ * (pt_image_alloc, same size everywhere).  On return the transfers are ENQUEUED that bring every other rank's bands
+ * into ctxs[root]'s accumulator, in place, each band once: one group of RCCL ncclSend / ncclRecv pairs over xGMI, the
+ * sends ordered after each rank's render on that rank's stream, the receives on the root's stream — pt_sync(ctxs[root])
+ * or pt_image_read*(ctxs[root], ...) waits for them.  Nothing needs to be zero anywhere; bytes moved = the image minus
+ * the root's own bands.  librccl is loaded on first use.  n <= 8; the ranks' GPUs must be pairwise distinct — or all
+ * the same one (a debugging arrangement: several contexts on one GPU), in which case the bands are device-to-device
+ * copies and RCCL is not involved.  Communicators are created once per device list and kept until the process ends. */
+int pt_combine_bands(pt_ctx *const *ctxs, int n, int root, int band_rows);
+
 /* Durations (ms) of the render kernels launched with record_timing since the last call, oldest first:
  * waits for those launches, writes up to `cap` values to ms[], stores the count in *n and empties the
  * ring.  No reference counterpart (the reference times with gettimeofday around its loop,

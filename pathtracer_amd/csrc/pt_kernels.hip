@@ -18,7 +18,11 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
 #include <cmath>
+#include <mutex>
 #include <vector>
 
 #define PT_NS pt_strict
@@ -708,6 +712,130 @@ extern "C" int pt_render_noalloc(pt_ctx *c, const pt_render_args *a) {
 	}
 	const RenderScratch rs = {dSeeds, (unsigned long long *)(sp + PT_SCRATCH_COUNTER_OFF), (unsigned int *)(sp + PT_SCRATCH_QUEUE_OFF)};
 	return launch_frames(c, a, img, st, rs, false);
+}
+
+// ---------------------------------------------------------------------------------------
+// Multi-GPU combine (include/pt_hip.h pt_combine_bands): the root's accumulator receives every other rank's
+// row bands — in place, each band exactly once — as ONE group of RCCL point-to-point transfers over xGMI.
+// librccl is loaded on first use (dlopen), so a single-GPU user never maps it.
+// ---------------------------------------------------------------------------------------
+namespace {
+struct RcclApi {
+	void *lib;
+	decltype(&ncclCommInitAll) commInitAll;
+	decltype(&ncclGroupStart) groupStart;
+	decltype(&ncclGroupEnd) groupEnd;
+	decltype(&ncclSend) send;
+	decltype(&ncclRecv) recv;
+	decltype(&ncclGetErrorString) errorString;
+};
+RcclApi g_rccl;
+std::mutex g_rcclLock;
+struct CommSet { int n; int dev[8]; ncclComm_t comm[8]; };
+std::vector<CommSet> g_comms;      // one set per distinct device list, kept for the life of the process
+
+int rccl_load() {
+	if(g_rccl.lib) return PT_OK;
+	const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+	void *lib = NULL;
+	for(const char *nm : names) if((lib = dlopen(nm, RTLD_NOW | RTLD_LOCAL))) break;
+	if(!lib) return fail(PT_E_DEVICE, "pt_combine_bands: cannot load librccl: %s", dlerror());
+	RcclApi a;
+	a.lib = lib;
+	a.commInitAll = (decltype(a.commInitAll))dlsym(lib, "ncclCommInitAll");
+	a.groupStart = (decltype(a.groupStart))dlsym(lib, "ncclGroupStart");
+	a.groupEnd = (decltype(a.groupEnd))dlsym(lib, "ncclGroupEnd");
+	a.send = (decltype(a.send))dlsym(lib, "ncclSend");
+	a.recv = (decltype(a.recv))dlsym(lib, "ncclRecv");
+	a.errorString = (decltype(a.errorString))dlsym(lib, "ncclGetErrorString");
+	if(!a.commInitAll || !a.groupStart || !a.groupEnd || !a.send || !a.recv || !a.errorString) {
+		dlclose(lib);
+		return fail(PT_E_DEVICE, "pt_combine_bands: librccl lacks a symbol%s", NULL);
+	}
+	g_rccl = a;
+	return PT_OK;
+}
+}   // namespace
+
+#define RCCL_TRY(expr)                                                                               \
+	do {                                                                                             \
+		ncclResult_t r_ = (expr);                                                                    \
+		if(r_ != ncclSuccess) {                                                                      \
+			snprintf(g_err, sizeof g_err, "%s failed: %s", #expr, g_rccl.errorString(r_));           \
+			return PT_E_DEVICE;                                                                      \
+		}                                                                                            \
+	} while(0)
+
+extern "C" int pt_combine_bands(pt_ctx *const *ctxs, int n, int root, int band_rows) {
+	if(!ctxs || n < 1 || n > 8 || root < 0 || root >= n || band_rows < 1) return fail(PT_E_INVALID, "pt_combine_bands: bad arguments%s", NULL);
+	for(int i = 0; i < n; i++) {
+		if(!ctxs[i] || !ctxs[i]->image) return fail(PT_E_STATE, "pt_combine_bands: a context has no accumulator (pt_image_alloc)%s", NULL);
+		if(ctxs[i]->imgW != ctxs[root]->imgW || ctxs[i]->imgH != ctxs[root]->imgH) return fail(PT_E_STATE, "pt_combine_bands: accumulators differ in size%s", NULL);
+	}
+	if(n == 1) return PT_OK;
+	pt_ctx *const R = ctxs[root];
+	const int W = R->imgW, H = R->imgH;
+	const int nb = (H + band_rows - 1) / band_rows;
+	// ranks that share the root's GPU (PT_SHARE_GPU debugging set-ups: several contexts on one device) cannot be RCCL
+	// peers of it; their bands are device-to-device copies on the root's stream, ordered after the rank's own stream
+	bool anyRemote = false, distinct = true;
+	for(int i = 0; i < n; i++) {
+		if(ctxs[i]->device != R->device) anyRemote = true;
+		for(int j = 0; j < i; j++) if(ctxs[i]->device == ctxs[j]->device) distinct = false;
+	}
+	if(anyRemote && !distinct) return fail(PT_E_INVALID, "pt_combine_bands: ranks must be on distinct GPUs, or all on one%s", NULL);
+	if(!anyRemote) {
+		HIP_TRY(hipSetDevice(R->device));
+		for(int i = 0; i < n; i++) {
+			if(i == root) continue;
+			HIP_TRY(hipEventRecord(ctxs[i]->evStop, ctxs[i]->stream));
+			HIP_TRY(hipStreamWaitEvent(R->stream, ctxs[i]->evStop, 0));
+		}
+		for(int b = 0; b < nb; b++) {
+			const int r = b % n;
+			if(r == root) continue;
+			const int row0 = b * band_rows, rows = row0 + band_rows <= H ? band_rows : H - row0;
+			const size_t off = (size_t)row0 * W, cnt = (size_t)rows * W;
+			HIP_TRY(hipMemcpyAsync(R->image + off, ctxs[r]->image + off, cnt * sizeof(float4), hipMemcpyDeviceToDevice, R->stream));
+		}
+		return PT_OK;
+	}
+	std::lock_guard<std::mutex> lock(g_rcclLock);
+	int rc = rccl_load();
+	if(rc != PT_OK) return rc;
+	CommSet *cs = NULL;
+	for(auto &c : g_comms) {
+		bool same = c.n == n;
+		for(int i = 0; same && i < n; i++) same = c.dev[i] == ctxs[i]->device;
+		if(same) { cs = &c; break; }
+	}
+	if(!cs) {
+		CommSet c;
+		c.n = n;
+		for(int i = 0; i < n; i++) c.dev[i] = ctxs[i]->device;
+		RCCL_TRY(g_rccl.commInitAll(c.comm, n, c.dev));      // one process drives all ranks
+		g_comms.push_back(c);
+		cs = &g_comms.back();
+	}
+	// every band not owned by the root: ncclSend on the owner's stream (ordered after its render), ncclRecv on the root's
+	// stream straight into the root's accumulator at the band's offset.  One group: the transfers run concurrently, each
+	// peer over its own xGMI link.  Bytes moved = the image minus the root's own bands, once.
+	RCCL_TRY(g_rccl.groupStart());
+	for(int b = 0; b < nb; b++) {
+		const int r = b % n;
+		if(r == root) continue;
+		const int row0 = b * band_rows, rows = row0 + band_rows <= H ? band_rows : H - row0;
+		const size_t off = (size_t)row0 * W, cnt = (size_t)rows * W * 4;
+		ncclResult_t e1 = g_rccl.send(ctxs[r]->image + off, cnt, ncclFloat, root, cs->comm[r], ctxs[r]->stream);
+		ncclResult_t e2 = g_rccl.recv(R->image + off, cnt, ncclFloat, r, cs->comm[root], R->stream);
+		if(e1 != ncclSuccess || e2 != ncclSuccess) {
+			(void)g_rccl.groupEnd();
+			snprintf(g_err, sizeof g_err, "pt_combine_bands: ncclSend/ncclRecv failed: %s", g_rccl.errorString(e1 != ncclSuccess ? e1 : e2));
+			return PT_E_DEVICE;
+		}
+	}
+	RCCL_TRY(g_rccl.groupEnd());
+	return PT_OK;
 }
 
 extern "C" int pt_kernel_times(pt_ctx *c, float *ms, int cap, int *n) {

@@ -71,6 +71,7 @@ typedef struct pt_encpool {
 typedef struct pt_backend {
 	int n;
 	pt_ctx *ctx[PT_MAX_GPUS];
+	int dev[PT_MAX_GPUS];                       /* HIP device of each rank (all 0 with PT_SHARE_GPU) */
 	int imgW[PT_MAX_GPUS], imgH[PT_MAX_GPUS];   /* size of each context's accumulator */
 	/* frame pipeline (PT_PIPELINE=k, k = 1..PT_MAX_PIPE): k worker threads per GPU, each with its own
 	 * context and stream, frames dealt round-robin.  k = 2 lets two small frames share one GPU: a
@@ -168,13 +169,18 @@ Renderer *create_renderer() {
 	int want = 1;
 	const char *env = getenv("PT_NUM_GPUS");
 	if(env && atoi(env) > 0) want = atoi(env);
-	if(want > devices) want = devices;
+	/* PT_SHARE_GPU=1 (debugging aid): PT_NUM_GPUS ranks even on fewer GPUs, ALL on GPU 0 — the band partition, the
+	 * per-rank launches and pt_combine_bands' merge run as they would on n GPUs (the merge as device copies, not RCCL) */
+	const char *share = getenv("PT_SHARE_GPU");
+	const int shared = share && atoi(share) > 0;
+	if(want > devices && !shared) want = devices;
 	if(want > PT_MAX_GPUS) want = PT_MAX_GPUS;
 
 	pt_backend *b = calloc(1, sizeof(pt_backend));
 	if(!b) { host_msg("Failed to allocate backend\n"); exit(1); }
 	for(int i = 0; i < want; i++) {
-		if(pt_ctx_create(i, &b->ctx[i]) != PT_OK) {
+		b->dev[i] = shared ? 0 : i;
+		if(pt_ctx_create(b->dev[i], &b->ctx[i]) != PT_OK) {
 			host_msg("Failed to create backend context on device %d: %s\n", i, pt_last_error());
 			exit(1);
 		}
@@ -350,19 +356,10 @@ Image *render(Renderer *renderer, int samples, int verbose) {
 	image->width = W; image->height = H;
 	image->data = malloc(3 * (size_t)W * (size_t)H);
 	if(!image->data) { free(image); return NULL; }
-	if(b->n == 1) {
-		if(pt_image_read_u8(b->ctx[0], NULL, 0, 0, image->data) != PT_OK) { destroy_image(image); return render_failed(renderer, "read-back"); }
-	} else {
-		unsigned char *tmp = malloc(3 * (size_t)W * (size_t)H);
-		if(!tmp) { destroy_image(image); return NULL; }
-		for(int i = 0; i < b->n; i++) {
-			if(pt_image_read_u8(b->ctx[i], NULL, 0, 0, tmp) != PT_OK) { free(tmp); destroy_image(image); return render_failed(renderer, "read-back"); }
-			for(int row = 0; row < H; row++)
-				if((row / PT_BAND_ROWS) % b->n == i)
-					memcpy(image->data + 3 * (size_t)W * row, tmp + 3 * (size_t)W * row, 3 * (size_t)W);
-		}
-		free(tmp);
-	}
+	/* several GPUs: the other ranks' bands travel into rank 0's accumulator over xGMI (one group of RCCL transfers,
+	 * pt_combine_bands), then ONE conversion and ONE 3-byte-per-pixel read-back, as with a single GPU */
+	if(b->n > 1 && samples > 0 && pt_combine_bands(b->ctx, b->n, 0, PT_BAND_ROWS) != PT_OK) { destroy_image(image); return render_failed(renderer, "combine"); }
+	if(pt_image_read_u8(b->ctx[0], NULL, 0, 0, image->data) != PT_OK) { destroy_image(image); return render_failed(renderer, "read-back"); }
 	return image;
 }
 
@@ -509,8 +506,9 @@ static int pipeline_submit(Renderer *renderer, int samples, const char *fileName
 	j->seeds = malloc(sizeof(uint64_t) * (size_t)(samples > 0 ? samples : 1));
 	j->fileName = strdup(fileName);
 	if(!j->flat || !j->seeds || !j->fileName) { job_free(j); return 0; }
-	for(int k = 0; k < samples; k++) j->seeds[k] = (uint64_t)seed_stream_next();   /* call order = frame order */
 	fill_render_args(&j->args, renderer);
+	/* everything that can fail comes first; the frame's seeds are drawn last, just before it is queued: a submit that
+	 * fails falls back to render(), which draws them itself, and the seed stream must not have moved twice */
 	if(!b->enc.started) {
 		pthread_mutex_init(&b->enc.lock, NULL); pthread_cond_init(&b->enc.wake, NULL); pthread_cond_init(&b->enc.room, NULL);
 		b->enc.head = b->enc.tail = NULL; b->enc.pending = 0; b->enc.quit = 0;
@@ -523,7 +521,7 @@ static int pipeline_submit(Renderer *renderer, int samples, const char *fileName
 	if(!w->started) {
 		if(g < b->n) { w->ctx = b->ctx[g]; w->imgW = b->imgW[g]; w->imgH = b->imgH[g]; }
 		else {
-			if(!b->extra[g] && pt_ctx_create(g % b->n, &b->extra[g]) != PT_OK) {
+			if(!b->extra[g] && pt_ctx_create(b->dev[g % b->n], &b->extra[g]) != PT_OK) {
 				host_msg("frame pipeline: %s\n", pt_last_error());
 				job_free(j);
 				return 0;
@@ -536,6 +534,7 @@ static int pipeline_submit(Renderer *renderer, int samples, const char *fileName
 		if(pthread_create(&w->thread, NULL, worker_main, w) != 0) { job_free(j); return 0; }
 		w->started = 1;
 	}
+	for(int k = 0; k < samples; k++) j->seeds[k] = (uint64_t)seed_stream_next();   /* call order = frame order */
 	pthread_mutex_lock(&w->lock);
 	while(w->pending >= PT_PIPE_DEPTH) pthread_cond_wait(&w->room, &w->lock);
 	if(w->tail) w->tail->next = j; else w->head = j;

@@ -43,7 +43,7 @@ _lib = None
 
 # every symbol include/pt_hip.h declares
 EXPORTS = ["pt_last_error", "pt_device_count", "pt_ctx_create", "pt_ctx_destroy", "pt_image_alloc",
-           "pt_scene_upload", "pt_render", "pt_render_noalloc", "pt_kernel_times", "pt_sync", "pt_image_read", "pt_image_read_u8", "pt_selftest"]
+           "pt_scene_upload", "pt_render", "pt_render_noalloc", "pt_combine_bands", "pt_kernel_times", "pt_sync", "pt_image_read", "pt_image_read_u8", "pt_selftest"]
 
 
 def load():
@@ -62,6 +62,7 @@ def load():
     lib.pt_scene_upload.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_int]
     lib.pt_render.argtypes = [C.c_void_p, C.POINTER(RenderArgs)]
     lib.pt_render_noalloc.argtypes = [C.c_void_p, C.POINTER(RenderArgs)]
+    lib.pt_combine_bands.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int]
     lib.pt_kernel_times.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_int)]
     lib.pt_sync.argtypes = [C.c_void_p]
     lib.pt_image_read.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
@@ -188,6 +189,12 @@ class Context:
         _check(self.lib.pt_selftest(self.h, op, pa.ctypes.data_as(u64p), pb.ctypes.data_as(u64p), pf.ctypes.data_as(fp),
                                     n, ou.ctypes.data_as(u64p), of.ctypes.data_as(fp)), "pt_selftest")
         return ou, of
+
+
+def combine_bands(ctxs, root, band_rows):
+    """pt_combine_bands over a list of Context objects (rank i = ctxs[i])."""
+    arr = (C.c_void_p * len(ctxs))(*[c.h for c in ctxs])
+    _check(load().pt_combine_bands(arr, len(ctxs), root, band_rows), "pt_combine_bands")
 
 
 def render_scene(ctx, scene, width, height, max_depth, seeds, **kw):

@@ -98,3 +98,80 @@ def test_scene_driver_frames_match_oracle(tmp_path, oracle, pipeline):
         got = read_png_rgb8(pat % i)
         assert np.array_equal(got, want), "frame %d: %d bytes differ" % (i, int((got != want).sum()))
         assert got.max() > 200
+
+
+def _driver_frames(tmp_path, env_extra, frames, W=96, H=54, spp=8):
+    env = dict(os.environ, PT_PIPELINE="0", **env_extra)
+    pat = str(tmp_path / "frame%d.png")
+    subprocess.check_call([os.path.join(PKG, "pt_scene_driver"), str(frames[0]), str(len(frames)), str(W), str(H), str(spp), "50", pat],
+                          env=env, cwd=str(tmp_path), timeout=200)
+    return [read_png_rgb8(pat % i) for i in frames]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ranks", [2, 3, 8])
+def test_band_ranks_on_one_gpu_merge_to_the_oracle_image(tmp_path, oracle, ranks):
+    """renderer.c's multi-rank path end to end on ONE GPU (PT_SHARE_GPU=1: PT_NUM_GPUS contexts on GPU 0): per-rank band
+    launches with global ids, pt_combine_bands' merge into rank 0's accumulator (device copies here, RCCL transfers
+    between distinct GPUs), one conversion, one read-back.  The PNGs must hold the oracle's 8-bit image."""
+    W, H, spp, frames = 96, 54, 8, (3, 4)
+    got = _driver_frames(tmp_path, {"PT_NUM_GPUS": str(ranks), "PT_SHARE_GPU": "1"}, frames)
+    stream = seedmod.glibc_rand_stream(len(frames) * spp)
+    for k, i in enumerate(frames):
+        want = oracle.postprocess(oracle.render(scenes.main_lua_frame(i), W, H, 50, stream[k * spp:(k + 1) * spp])).reshape(H, W, 3)
+        assert np.array_equal(got[k], want), "ranks %d frame %d: %d bytes differ" % (ranks, i, int((got[k] != want).sum()))
+
+
+@pytest.mark.gpu
+def test_two_gpus_combine_over_rccl(tmp_path, oracle):
+    """PT_NUM_GPUS=2 on two DISTINCT GPUs: the bands of GPU 1 reach GPU 0 through pt_combine_bands' RCCL send/recv group.
+    Skipped on a one-GPU box (the driver's multi-GPU node runs it)."""
+    from pathtracer_amd import hip
+    if hip.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    W, H, spp, frames = 96, 54, 8, (3, 4)
+    got = _driver_frames(tmp_path, {"PT_NUM_GPUS": "2"}, frames)
+    stream = seedmod.glibc_rand_stream(len(frames) * spp)
+    for k, i in enumerate(frames):
+        want = oracle.postprocess(oracle.render(scenes.main_lua_frame(i), W, H, 50, stream[k * spp:(k + 1) * spp])).reshape(H, W, 3)
+        assert np.array_equal(got[k], want), "frame %d: %d bytes differ" % (i, int((got[k] != want).sum()))
+
+
+@pytest.mark.gpu
+def test_combine_bands_through_the_c_abi(ctx, oracle):
+    """pt_combine_bands called directly: three contexts on one GPU render their bands of a frame, the merge lands in the
+    root's accumulator; bad arguments are refused."""
+    from pathtracer_amd import hip
+    sc = scenes.glass_lattice()
+    s = seedmod.glibc_rand_stream(5)
+    W, H, band = 80, 45, 4
+    full = hip.render_scene(ctx, sc, W, H, 32, s)
+    ranks = [hip.Context(0) for _ in range(3)]
+    try:
+        for r, c in enumerate(ranks):
+            c.scene_upload(sc["spheres"])
+            c.image_alloc(W, H)
+            c.render(sc, W, H, 32, s, rank=r, world=3, band_rows=band, async_=True)
+        hip.combine_bands(ranks, 1, band)
+        got = ranks[1].image_read()
+        assert np.array_equal(got[..., :3].view(np.uint32), full[..., :3].view(np.uint32))
+        with pytest.raises(hip.PtError):
+            hip.combine_bands(ranks, 3, band)
+        ranks[2].image_alloc(W, H + 1)
+        with pytest.raises(hip.PtError):
+            hip.combine_bands(ranks, 0, band)
+    finally:
+        for c in ranks:
+            c.close()
+
+
+@pytest.mark.gpu
+def test_bench_rccl_path_executes_with_one_rank(tmp_path):
+    """bench.py's N > 1 code path (process group, zero-fill, RCCL reduce, barrier, frame check) with a single rank."""
+    import sys
+    out = subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--force-dist", "--steps", "2", "--warmup", "1",
+                                   "--spp", "4", "--no-cpu-baseline", "--no-fast-math"], cwd=str(tmp_path), timeout=300,
+                                  env=dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29617"))
+    import json
+    line = json.loads(out.decode().strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["config"]["verified_rows"] == 6 and line["value"] > 0
