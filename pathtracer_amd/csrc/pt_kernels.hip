@@ -826,8 +826,12 @@ extern "C" int pt_combine_bands(pt_ctx *const *ctxs, int n, int root, int band_r
 		if(r == root) continue;
 		const int row0 = b * band_rows, rows = row0 + band_rows <= H ? band_rows : H - row0;
 		const size_t off = (size_t)row0 * W, cnt = (size_t)rows * W * 4;
+		// each call with its communicator's device current (one process drives all ranks)
+		hipError_t d1 = hipSetDevice(ctxs[r]->device);
 		ncclResult_t e1 = g_rccl.send(ctxs[r]->image + off, cnt, ncclFloat, root, cs->comm[r], ctxs[r]->stream);
+		hipError_t d2 = hipSetDevice(R->device);
 		ncclResult_t e2 = g_rccl.recv(R->image + off, cnt, ncclFloat, r, cs->comm[root], R->stream);
+		if(d1 != hipSuccess || d2 != hipSuccess) { (void)g_rccl.groupEnd(); return fail(PT_E_DEVICE, "pt_combine_bands: hipSetDevice failed%s", NULL); }
 		if(e1 != ncclSuccess || e2 != ncclSuccess) {
 			(void)g_rccl.groupEnd();
 			snprintf(g_err, sizeof g_err, "pt_combine_bands: ncclSend/ncclRecv failed: %s", g_rccl.errorString(e1 != ncclSuccess ? e1 : e2));
