@@ -574,6 +574,25 @@ static int launch_frames(pt_ctx *c, const pt_render_args *a, float4 *img, hipStr
 		}
 		if((long long)a->first_frame + a->n_frames >= (1 << 24)) want = 0;      // the group accumulation counts frames in float
 		p.logS = want;
+		// The tail of the launch: blocks last nFrames / S rounds and the chip drains over about one block time at the
+		// end, so the pixels whose blocks are dispatched last get more lanes each (shorter blocks; bit-identical).
+		// Measured on the headline frame: 4 lanes everywhere 162.3 ms, 8 everywhere 162.4 (what the tail gains the
+		// ordered accumulation, repeated by every lane of a group, gives back), 4 + the last 8 % at 16: see DESIGN.md §4.
+		int want2 = want;
+		const char *tp = getenv("PT_TAIL_PCT");      // debugging aid: share of the pixels in the second tier, 0 = none
+		const int pct = tp ? atoi(tp) : 8;
+		const bool floatFrames = (long long)a->first_frame + a->n_frames < (1 << 24);      // as for the first tier
+		if(!fs && pct > 0 && floatFrames) while(want2 < 4 && (2 << want2) <= a->n_frames) want2++;
+		long long tier = lp;
+		if(want2 > want) {
+			tier = lp - lp * pct / 100;
+			tier -= tier % 64;                      // tier << logS is a multiple of the block size (256) for logS >= 2
+			if(want < 2) tier -= tier % 256;
+			if(tier < 0) tier = 0;
+		}
+		p.logS2 = want2;
+		p.tierPixels = (int)tier;
+		p.tierThreads = (int)(tier << want);
 	}
 	// LDS kernel: trios of the table that hold a sphere much smaller than the largest one get a wave-level "can any
 	// lane hit it" test per sphere before the sqrt/select part (closest_hit_lds); a pure speed heuristic, same image.
@@ -589,7 +608,7 @@ static int launch_frames(pt_ctx *c, const pt_render_args *a, float4 *img, hipStr
 	LaunchArgs la;
 	la.image = img; la.p = p; la.sc = sc; la.seedmul = rs.seedmul; la.bounceCounter = rs.counter; la.queue = rs.queue;
 	la.stream = st; la.count = a->bounce_count != NULL;
-	la.gridPixels = (unsigned)(((lp << p.logS) + 255) / 256);
+	la.gridPixels = (unsigned)((((long long)p.tierThreads + ((lp - p.tierPixels) << p.logS2)) + 255) / 256);
 	// Up to PT_LOCKSTEP_MAX_SPHERES spheres: the lock-step kernel with the whole table in LDS and a branch-free
 	// scan (the reference's own scene has 9).  Beyond that the persistent streaming kernel wins on open scenes even
 	// where the table would still fit in LDS, because paths end after a few bounces and its lanes never idle (1080p,

@@ -23,6 +23,7 @@ struct KParams {
 	int rank, world, bandRows;          // row-band partition (pt_hip.h)
 	int localPixels;                    // pixels of this rank
 	int logS;                           // LDS kernel: 2^logS lanes share a pixel (sample-interleaved)
+	int logS2, tierPixels, tierThreads; // LDS kernel: pixels from tierPixels on (threads from tierThreads on) use 2^logS2 lanes
 	unsigned trioSkipMask;              // LDS kernel: bit t = trio t of the table holds a small sphere (closest_hit_lds)
 };
 

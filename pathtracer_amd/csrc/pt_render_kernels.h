@@ -439,11 +439,17 @@ __global__ PT_LDS_BOUNDS void pt_render_lds_kernel(float4 *__restrict__ image, c
 	// (every lane of the group redundantly, a few dozen instructions).  Bit-identical to S = 1; it only
 	// multiplies the number of waves for images that cannot fill the chip on their own (a 640x360 frame,
 	// or one GPU's bands of a 1080p frame split 8 ways, is ~4000 waves for 8192 wave slots).
-	const int S = 1 << p.logS;
-	const int thread = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+	// Two tiers of a launch: the first p.tierPixels pixels of the rank at 2^logS lanes each, the rest — the blocks that
+	// are dispatched LAST — at 2^logS2 >= 2^logS lanes each.  A block lasts nFrames / S rounds, and the end of a launch
+	// is spent waiting for the last blocks while the chip drains: shorter blocks there cut that tail (pt_render).
+	// A block never straddles the tiers (tierThreads is a multiple of the block size).
+	int thread = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+	int logS = p.logS, pixelBase = 0;
+	if(thread >= p.tierThreads) { thread -= p.tierThreads; logS = p.logS2; pixelBase = p.tierPixels; }
+	const int S = 1 << logS;
 	const int sub = thread & (S - 1);
 	const int groupBase = (int)(threadIdx.x & 63) & ~(S - 1);
-	const int id = pixel_id(p, thread >> p.logS);
+	const int id = pixel_id(p, pixelBase + (thread >> logS));
 	unsigned int myBounces = 0;
 	if(id >= 0) {
 		const f3 origin = camera_origin(p, id);

@@ -239,6 +239,32 @@ def test_sample_interleaved_lanes_are_bit_identical(ctx, oracle):
         os.environ.pop("PT_LANES_PER_PIXEL", None)
 
 
+def test_two_tier_launch_is_bit_identical(ctx, oracle):
+    """pt_render gives the pixels whose blocks are dispatched last more lanes each (shorter blocks at the end of the
+    launch; PT_TAIL_PCT sets their share, 0 = one tier).  Any share must give the bits of the one-tier launch, also for
+    a rank's bands and for a continued accumulator."""
+    sc = scenes.main_lua_frame(0)
+    W, H = 1920, 1080
+    s = seedmod.glibc_rand_stream(24)
+    try:
+        os.environ["PT_TAIL_PCT"] = "0"
+        ref, bc = hip.render_scene(ctx, sc, W, H, 50, s, count_bounces=True)
+        want = oracle.render(sc, W, H, 50, s, id_begin=1079 * W, id_end=1080 * W)
+        assert np.array_equal(bits(ref[1079, :, :3]), bits(want[1079, :, :3]))
+        for pct in (8, 37, 100):
+            os.environ["PT_TAIL_PCT"] = str(pct)
+            img, b2 = hip.render_scene(ctx, sc, W, H, 50, s, count_bounces=True)
+            assert np.array_equal(bits(img), bits(ref)) and b2 == bc, pct
+            ctx.image_alloc(W, H)
+            for r in range(3):
+                ctx.render(sc, W, H, 50, s[:16], rank=r, world=3, band_rows=7)
+            for r in range(3):
+                ctx.render(sc, W, H, 50, s[16:], first_frame=16, rank=r, world=3, band_rows=7)
+            assert np.array_equal(bits(ctx.image_read()[..., :3]), bits(ref[..., :3])), pct
+    finally:
+        os.environ.pop("PT_TAIL_PCT", None)
+
+
 def test_u8_epilogue(ctx, oracle):
     g = np.load(os.path.join(GOLD, "frame0_64x36.npz"))
     sc = {"spheres": g["spheres"], "bg": g["bg"], "cam": g["cam"]}
