@@ -582,7 +582,11 @@ static int launch_frames(pt_ctx *c, const pt_render_args *a, float4 *img, hipStr
 		const char *tp = getenv("PT_TAIL_PCT");      // debugging aid: share of the pixels in the second tier, 0 = none
 		const int pct = tp ? atoi(tp) : 8;
 		const bool floatFrames = (long long)a->first_frame + a->n_frames < (1 << 24);      // as for the first tier
-		if(!fs && pct > 0 && floatFrames) while(want2 < 4 && (2 << want2) <= a->n_frames) want2++;
+		// 16 lanes at most, or 32 where the first tier already has 16 (a small launch, e.g. one rank's band of
+		// eight: 21.39 -> 21.2 ms); PT_TAIL_LANES (a debugging aid) overrides the log2 of that limit.
+		const char *tl = getenv("PT_TAIL_LANES");
+		const int cap2 = tl ? atoi(tl) : want >= 4 ? 5 : 4;
+		if(!fs && pct > 0 && floatFrames) while(want2 < cap2 && want2 < 5 && (2 << want2) <= a->n_frames) want2++;
 		long long tier = lp;
 		if(want2 > want) {
 			tier = lp - lp * pct / 100;

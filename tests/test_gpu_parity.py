@@ -261,6 +261,16 @@ def test_two_tier_launch_is_bit_identical(ctx, oracle):
             for r in range(3):
                 ctx.render(sc, W, H, 50, s[16:], first_frame=16, rank=r, world=3, band_rows=7)
             assert np.array_equal(bits(ctx.image_read()[..., :3]), bits(ref[..., :3])), pct
+        # a small launch: the first tier already has 16 lanes per pixel, the second 32
+        s = seedmod.glibc_rand_stream(64)
+        os.environ["PT_TAIL_PCT"] = "0"
+        ref, bc = hip.render_scene(ctx, sc, 640, 360, 50, s, count_bounces=True)
+        want = oracle.render(sc, 640, 360, 50, s, id_begin=358 * 640, id_end=360 * 640)
+        assert np.array_equal(bits(ref[358:, :, :3]), bits(want[358:, :, :3]))
+        for pct in (8, 50):
+            os.environ["PT_TAIL_PCT"] = str(pct)
+            img, b2 = hip.render_scene(ctx, sc, 640, 360, 50, s, count_bounces=True)
+            assert np.array_equal(bits(img), bits(ref)) and b2 == bc, pct
     finally:
         os.environ.pop("PT_TAIL_PCT", None)
 
