@@ -174,7 +174,10 @@ int pt_image_read_u8(pt_ctx *ctx, const void *d_image, int width, int height, un
  *   op 10: as op 7 for the lock-step kernel's form of the divide: den = a = |d|^2 formed from x = dot(d, d) as the
  *         kernel forms it (src/cl/ray.cl:73), the reciprocal seeded with v_rsq_f32(x)^2
  *   op 11: same ranges as op 4: out_u64[i] = #patterns x where normalize()'s 1 / length (one v_rsq_f32 for root and
- *         reciprocal) differs from 1.0f / sqrtf(x) */
+ *         reciprocal) differs from 1.0f / sqrtf(x)
+ *   op 12: out_u64[i] = #significands x of the binade with exponent field b[i] where the running mean's divide by
+ *         f1 = a[i] (src/cl/main.cl:29 with frame + 1 = a[i] < 2^24) in its two-FMA form differs from x / f1
+ *         (b[i] | 0x100: the same with a reciprocal 256 ulps off, a canary that must report differences) */
 int pt_selftest(pt_ctx *ctx, int op, const uint64_t *a, const uint64_t *b, const float *in_f,
                 int n, uint64_t *out_u64, float *out_f);
 

@@ -182,6 +182,18 @@ __global__ void pt_selftest_kernel(int op, const uint64_t *a, const uint64_t *b,
 			if(want != want ? (got == got) : (__float_as_uint(got) != __float_as_uint(want))) bad++;
 		}
 		ou[i] = bad;
+	} else if(op == 12) {
+		// the split running mean's divide (pt_render_kernels.h mean_step) against x / f1: f1 = (float)a[i] (an integer
+		// below 2^24), x = every significand of the binade with exponent field b[i]: #x where they differ
+		// (b[i] & 0x100: with r 256 ulps too large instead, which must show up — the tests' canary; the form absorbs a few ulps)
+		const float f1 = (float)a[i], r = __uint_as_float(__float_as_uint(1.0f / f1) + (uint32_t)(b[i] & 0x100));
+		const uint32_t e = (uint32_t)(b[i] & 0xff) << 23;
+		uint64_t bad = 0;
+		for(uint32_t m = 0; m < (1u << 23); m++) {
+			const float x = __uint_as_float(e | m);
+			if(__float_as_uint(mean_step(0.0f, x, f1 - 1.0f, f1, r)) != __float_as_uint(x / f1)) bad++;
+		}
+		ou[i] = bad;
 	}
 }
 
@@ -586,7 +598,7 @@ static int launch_frames(pt_ctx *c, const pt_render_args *a, float4 *img, hipStr
 		// eight: 21.39 -> 21.2 ms); PT_TAIL_LANES (a debugging aid) overrides the log2 of that limit.
 		const char *tl = getenv("PT_TAIL_LANES");
 		const int cap2 = tl ? atoi(tl) : want >= 4 ? 5 : 4;
-		if(!fs && pct > 0 && floatFrames) while(want2 < cap2 && want2 < 5 && (2 << want2) <= a->n_frames) want2++;
+		if((!fs || tp) && pct > 0 && floatFrames) while(want2 < cap2 && want2 < 5 && (2 << want2) <= a->n_frames) want2++;
 		long long tier = lp;
 		if(want2 > want) {
 			tier = lp - lp * pct / 100;
@@ -918,7 +930,7 @@ extern "C" int pt_image_read_u8(pt_ctx *c, const void *d_image, int width, int h
 
 extern "C" int pt_selftest(pt_ctx *c, int op, const uint64_t *a, const uint64_t *b, const float *in_f, int n,
                            uint64_t *out_u64, float *out_f) {
-	if(!c || n <= 0 || op < 0 || op > 11) return fail(PT_E_INVALID, "pt_selftest: bad arguments%s", NULL);
+	if(!c || n <= 0 || op < 0 || op > 12) return fail(PT_E_INVALID, "pt_selftest: bad arguments%s", NULL);
 	HIP_TRY(hipSetDevice(c->device));
 	uint64_t *da = NULL, *db = NULL, *dou = NULL;
 	float *dif = NULL, *dof = NULL;

@@ -62,6 +62,23 @@ PT_DEV f3 accumulate(f3 acc, f3 color, const KParams &p, int frame) {
 	return running_mean(acc, expose(color, p), (float)frame, (float)(frame + 1));
 }
 
+// The running mean when S >= 4 lanes share a pixel (pt_render_lds_kernel): x / f1 as q = x * r, q' = fma(fma(-q, f1, x), r, q)
+// with r = RN(1 / f1).  q' is the correctly rounded quotient for EVERY significand of x and every integer f1 checked
+// (tools/probe/meandiv_probe.c: all 2^23 significands for f1 = 1 .. 65536, the top 4096 divisors below 2^24 and
+// every 4099th in between; Markstein's theorem gives it for the rest) as long as nothing under- or overflows, which
+// mean_safe() guarantees: with every colour component 0 or in [2^-40, 2^40] the mean stays in [2^-64, 2^40], x in
+// [2^-64, 2^65], and the residual is a multiple of ulp(q) >= 2^-111.
+PT_DEV bool mean_safe(f3 c) {
+	const uint32_t x = __float_as_uint(c.x), y = __float_as_uint(c.y), z = __float_as_uint(c.z);
+	const uint32_t hi = max(max(x, y), z), lo = min(min(x - 1u, y - 1u), z - 1u);      // 0 - 1 wraps to the top: 0 passes
+	return hi <= 0x53800000u && lo >= 0x2B7FFFFFu;                                     // negative, NaN, inf: hi fails
+}
+PT_DEV float mean_step(float acc, float c, float f, float f1, float r) {               // main.cl:29, one channel
+	const float x = acc * f + c;
+	const float q = x * r;
+	return __builtin_fmaf(__builtin_fmaf(-q, f1, x), r, q);
+}
+
 // src/cl/ray.cl:117-171 — everything after the closest hit is known.  Returns true when the path
 // ends here (front face of a light), with its colour in `color`.
 PT_DEV bool shade_hit(Path &pt, float t, const float4 g, const float4 mA, const float4 mB, f3 &color) {
@@ -451,6 +468,12 @@ __global__ PT_LDS_BOUNDS void pt_render_lds_kernel(float4 *__restrict__ image, c
 	const int groupBase = (int)(threadIdx.x & 63) & ~(S - 1);
 	const int id = pixel_id(p, pixelBase + (thread >> logS));
 	unsigned int myBounces = 0;
+	// S >= 4: the ordered mean is split by channel.  After a round every lane leaves {colour, r = 1 / (its frame + 1)}
+	// in meanSlot (wave-private rows: a group never spans waves), then lane `sub` of a group runs channel min(sub, 2)
+	// through the round's S steps at 5 instructions each (mean_step) instead of all three channels at ~10 each with
+	// an IEEE divide per step; lanes 0..2 of the group hold the pixel's mean.  One launch-long switch per wave
+	// (`split`): it falls back to the plain form for good the first time a lane sees a value outside mean_safe().
+	__shared__ float4 meanSlot[2 * 256];
 	if(id >= 0) {
 		const f3 origin = camera_origin(p, id);
 		f3 acc = mk3(0.0f, 0.0f, 0.0f);
@@ -458,6 +481,10 @@ __global__ PT_LDS_BOUNDS void pt_render_lds_kernel(float4 *__restrict__ image, c
 			float4 v = image[id];
 			acc = mk3(v.x, v.y, v.z);
 		}
+		const int ch = sub < 2 ? sub : 2;
+		bool split = S >= 4 && __ballot(!mean_safe(acc)) == 0;
+		float accCh = ch == 0 ? acc.x : ch == 1 ? acc.y : acc.z;
+		const float2 *const rd = (const float2 *)meanSlot + ((int)(threadIdx.x & ~(unsigned)(S - 1)) * 4 + ch);
 		for(int k0 = 0; k0 < p.nFrames; k0 += S) {
 			const int k = k0 + sub;
 			f3 color = mk3(0.0f, 0.0f, 0.0f);                                            // ray.cl:92
@@ -485,12 +512,32 @@ __global__ PT_LDS_BOUNDS void pt_render_lds_kernel(float4 *__restrict__ image, c
 				const int round = p.nFrames - k0 < S ? p.nFrames - k0 : S;
 				color = expose(color, p);
 				float f = (float)(p.firstFrame + k0);      // frame numbers stay below 2^24 when S > 1 (pt_render): f + 1.0f is exact
-				for(int s = 0; s < round; s++, f += 1.0f) {
-					const f3 c = mk3(__shfl(color.x, groupBase + s, 64), __shfl(color.y, groupBase + s, 64), __shfl(color.z, groupBase + s, 64));
-					acc = running_mean(acc, c, f, f + 1.0f);
+				if(split && __ballot(!mean_safe(color)) != 0) {
+					split = false;
+					acc = mk3(__shfl(accCh, groupBase, 64), __shfl(accCh, groupBase + 1, 64), __shfl(accCh, groupBase + 2, 64));
 				}
+				if(split) {
+					const float r = pt_div(1.0f, f + (float)(sub + 1));
+					meanSlot[2 * threadIdx.x] = make_float4(color.x, r, color.y, r);
+					meanSlot[2 * threadIdx.x + 1] = make_float4(color.z, r, 0.0f, 0.0f);
+					__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+					__builtin_amdgcn_wave_barrier();
+					__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll 4
+					for(int s = 0; s < round; s++, f += 1.0f) {
+						const float2 cr = rd[4 * s];
+						accCh = mean_step(accCh, cr.x, f, f + 1.0f, cr.y);
+					}
+					__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+					__builtin_amdgcn_wave_barrier();
+				} else
+					for(int s = 0; s < round; s++, f += 1.0f) {
+						const f3 c = mk3(__shfl(color.x, groupBase + s, 64), __shfl(color.y, groupBase + s, 64), __shfl(color.z, groupBase + s, 64));
+						acc = running_mean(acc, c, f, f + 1.0f);
+					}
 			}
 		}
+		if(split) acc = mk3(__shfl(accCh, groupBase, 64), __shfl(accCh, groupBase + 1, 64), __shfl(accCh, groupBase + 2, 64));
 		if(COUNT && S > 1) {
 			unsigned int v = myBounces, tot = 0;
 			for(int s = 0; s < S; s++) tot += (unsigned int)__shfl((int)v, groupBase + s, 64);

@@ -97,6 +97,29 @@ def test_normalize_reciprocal_length_on_every_float(ctx):
     assert len(bad) == 0, "inv_len(x) != 1/sqrtf(x) in %d chunks, first at bits 0x%08x" % (len(bad), int(bad[0]) << 16)
 
 
+def test_running_mean_divide_on_every_significand(ctx):
+    """The split running mean divides by frame + 1 as q = x * r, q' = fma(fma(-q, f1, x), r, q), r = RN(1 / f1)
+    (pt_render_kernels.h mean_step).  On the device, against x / f1: every significand of x for f1 = 1 .. 4096 in one
+    binade, and at both ends of the range mean_safe() allows x (2^-64, 2^65) for divisors of every shape up to 2^24 - 1.
+    tools/probe/meandiv_probe.c walks f1 = 1 .. 65536 the same way on the CPU (tests/test_meandiv_exhaustive.py runs a
+    slice)."""
+    div = list(range(1, 4097))
+    exp = [127] * len(div)
+    shapes = sorted({(1 << k) + d for k in range(1, 24) for d in (-1, 0, 1)} | {(1 << 24) - 1, 4097, 65535, 65537,
+                    1000003, 9999991, 16777213, 12345679, 11184811, 5592405, 3 * 5 * 7 * 11 * 13 * 17})
+    for e in (63, 191):
+        div += shapes
+        exp += [e] * len(shapes)
+    assert max(div) < (1 << 24)
+    div += [1000003, 9999991]                    # canary: a reciprocal 256 ulps off must be noticed
+    exp += [127 | 0x100] * 2
+    ou, _ = ctx.selftest(12, a=np.asarray(div, np.uint64), b=np.asarray(exp, np.uint64))
+    assert ou[-1] > 1000 and ou[-2] > 1000, ou[-2:]
+    bad = np.nonzero(ou[:-2])[0]
+    assert len(bad) == 0, "mean_step != x / f1 for %d divisors, first f1 = %d (%d significands)" % (
+        len(bad), div[bad[0]], int(ou[bad[0]]))
+
+
 def test_short_reciprocal_is_the_divide_on_every_float(ctx):
     """pt_device.h rcp_cr (v_rcp_f32 + two FMA steps, full divide outside the normal range) == 1.0f / x on all 2^32 patterns."""
     n = 1 << 16
@@ -235,6 +258,39 @@ def test_sample_interleaved_lanes_are_bit_identical(ctx, oracle):
             ctx.render(sc, 96, 54, 32, stream[:5])
             ctx.render(sc, 96, 54, 32, stream[5:13], first_frame=5)
             assert np.array_equal(bits(ctx.image_read()[..., :3]), bits(ref[13][0][..., :3])), lanes
+    finally:
+        os.environ.pop("PT_LANES_PER_PIXEL", None)
+
+
+def test_split_running_mean_and_its_fallback(ctx, oracle):
+    """With 4 or more lanes per pixel the ordered running mean (main.cl:29) is split by channel and divides by
+    frame + 1 as two FMAs around RN(1 / (frame + 1)) (pt_render_kernels.h mean_step; exhaustively checked on the CPU by
+    tools/probe/meandiv_probe.c), for colours that are 0 or in [2^-40, 2^40]; a wave that meets anything else goes back to
+    the plain divide for the rest of the launch.  Dark walls (albedo 0.02: a path that finds the light after k bounces
+    carries 10 * 0.02^k, down to denormals and 0) make waves switch at different rounds; extreme exposures make every wave
+    switch at once; a continued accumulator checks the values loaded from the image."""
+    base = scenes.main_lua_frame(0)
+    dark = {k: v.copy() for k, v in base.items()}
+    dark["spheres"][:6, 5:8] *= np.float32(0.02)
+    cases = [("dark", dark)]
+    for name, expo in (("tiny", 1e-20), ("huge", 1e25), ("denormal", 1e-36)):
+        sc = {k: v.copy() for k, v in base.items()}
+        sc["cam"][9] = np.float32(expo)
+        cases.append((name, sc))
+    s = seedmod.glibc_rand_stream(48)
+    try:
+        for name, sc in cases:
+            want = oracle.render(sc, 96, 54, 50, s)
+            for lanes in (4, 16, 32):
+                os.environ["PT_LANES_PER_PIXEL"] = str(lanes)
+                img = hip.render_scene(ctx, sc, 96, 54, 50, s)
+                assert np.array_equal(bits(img[..., :3]), bits(want[..., :3])), (name, lanes)
+                ctx.image_alloc(96, 54)
+                ctx.render(sc, 96, 54, 50, s[:19])
+                ctx.render(sc, 96, 54, 50, s[19:], first_frame=19)
+                assert np.array_equal(bits(ctx.image_read()[..., :3]), bits(want[..., :3])), (name, lanes, "continued")
+        v = want[..., :3]
+        assert np.isfinite(v).all()
     finally:
         os.environ.pop("PT_LANES_PER_PIXEL", None)
 
