@@ -452,8 +452,8 @@ __global__ PT_LDS_BOUNDS void pt_render_lds_kernel(float4 *__restrict__ image, c
 	// Sample-interleaved lanes: a pixel is served by S = 1 << p.logS adjacent lanes, lane `sub` tracing the
 	// samples k = sub (mod S).  The samples of a pixel are independent paths (src/cl/main.cl:6: the RNG
 	// stream depends on (id, seed_k) only); what is serial is the running mean, so after every round of S
-	// samples each lane collects the S colours by shuffles and accumulates them IN ORDER k, k+1, ...
-	// (every lane of the group redundantly, a few dozen instructions).  Bit-identical to S = 1; it only
+	// samples the group accumulates the S colours IN ORDER k, k+1, ... (S >= 4: one channel per lane, see
+	// meanSlot below; S = 2: every lane all three, collected by shuffles).  Bit-identical to S = 1; it only
 	// multiplies the number of waves for images that cannot fill the chip on their own (a 640x360 frame,
 	// or one GPU's bands of a 1080p frame split 8 ways, is ~4000 waves for 8192 wave slots).
 	// Two tiers of a launch: the first p.tierPixels pixels of the rank at 2^logS lanes each, the rest — the blocks that
