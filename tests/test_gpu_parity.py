@@ -483,6 +483,39 @@ def test_config5_lattice_full_size_rows(ctx, oracle):
     assert 20.0 < bc / (W * H * 2) < 32.0
 
 
+def test_config4_one_rank_at_its_full_sample_count(ctx, oracle):
+    """BASELINE config 4 as one of eight ranks runs it: 3840x2160, 1024 spp (64 rounds of 16 lanes per pixel, the last
+    bands at 32), bands of 8 rows, rank 3.  One row of the rank's bands against the oracle at the full 1024 spp, bit for
+    bit; rows of other ranks stay untouched."""
+    sc = scenes.main_lua_frame(0)
+    W, H, spp = 3840, 2160, 1024
+    s = seedmod.glibc_rand_stream(spp)
+    ctx.scene_upload(sc["spheres"])
+    ctx.image_alloc(W, H)
+    ctx.render(sc, W, H, 50, s, rank=3, world=8, band_rows=8)
+    img = ctx.image_read()
+    r = 8 * (3 + 8 * 20) + 5                       # a row of rank 3's 21st band
+    want = oracle.render(sc, W, H, 50, s, id_begin=r * W, id_end=(r + 1) * W, nthreads=16)
+    assert np.array_equal(bits(img[r, :, :3]), bits(want[r, :, :3])), mismatch_report(img[r, :, :3], want[r, :, :3])
+    assert not img[8 * 4:8 * 11].any()             # bands of ranks 4..7, 0..2: still the cleared accumulator
+
+
+def test_config5_and_config3_at_their_full_sample_counts(ctx, oracle):
+    """BASELINE config 5 (glass lattice, depth 32, 1080p, 64 spp) and config 3 (10^4 random spheres, 1080p, 64 spp) as
+    DESIGN.md section 6 times them: a row / segments of the frame against the oracle at the full sample count."""
+    W, H, spp = 1920, 1080, 64
+    s = seedmod.glibc_rand_stream(spp)
+    sc = scenes.glass_lattice()
+    img = hip.render_scene(ctx, sc, W, H, 32, s)
+    want = oracle.render(sc, W, H, 32, s, id_begin=540 * W, id_end=541 * W, nthreads=16)
+    assert np.array_equal(bits(img[540, :, :3]), bits(want[540, :, :3])), mismatch_report(img[540, :, :3], want[540, :, :3])
+    sc = scenes.dense_random(10000)
+    flat = hip.render_scene(ctx, sc, W, H, 50, s).reshape(-1, 4)
+    for start in (0, 540 * W + 928, 1079 * W + 1856):
+        want = oracle.render(sc, W, H, 50, s, id_begin=start, id_end=start + 64, nthreads=16).reshape(-1, 4)
+        assert np.array_equal(bits(flat[start:start + 64, :3]), bits(want[start:start + 64, :3])), "pixels %d.." % start
+
+
 @pytest.mark.parametrize("kernel", ["lds", "stream"])
 @pytest.mark.parametrize("name", sorted(n for n in CASES if not n.startswith(("dense3000", "dense513", "empty"))))
 def test_both_kernels_on_every_small_fixture(ctx, kernel, name):
