@@ -12,7 +12,7 @@
  * Parity pin: bit-exact against oracle/_ref/libptref_strict.so (the reference kernel
  * compiled verbatim for x86 without fast-math flags) and within 1e-5 of
  * libptref_fast.so (the reference's own -cl-fast-relaxed-math flags) — checked by
- * tests/test_oracle_vs_ref.py here and frozen into tests/golden/ for the GPU box.
+ * tests/test_oracle_golden.py (test_oracle_vs_live_reference_build) here and frozen into tests/golden/ for the GPU box.
  */
 #include <math.h>
 #include <pthread.h>
