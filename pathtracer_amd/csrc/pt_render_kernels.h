@@ -225,10 +225,17 @@ PT_DEV void test_sphere(const float4 g, int i, f3 o, f3 d, float a, uint32_t &be
 	candidate_update(bHalf, disc, i, best, prev, idx, tiny);
 }
 
+// "This lane can hit the sphere" as a sign bit: disc >= 0 and bHalf < 0, i.e. sign(disc) clear and sign(bHalf) set, in
+// full-rate bit operations (the float form, min(disc, -bHalf) >= 0 over four spheres, is four v_min, three v_max and a
+// compare, all half rate).  What the sign test leaves out beyond that form is no hit in the reference either:
+// bHalf == +0 gives num = -sqrt(disc) <= 0; a NaN disc gives a NaN t (ray.cl:78,82 are both false); and disc is never
+// -0 (bHalf * bHalf is +0 or larger, and x - y rounds to -0 only for x == -0).
+PT_DEV int can_hit(float bHalf, float disc) { return (int)(~__float_as_uint(disc) & __float_as_uint(bHalf)); }
+
 // Scan of one LDS-staged chunk for tables too large to unroll against (dense scenes): most spheres are
 // missed by every ray of the wave, so the sqrt/select part runs only for a group of four in which some
 // lane can hit something.  A sphere can only be hit if disc >= 0 and bHalf < 0 (then -bHalf > sqrt(disc)
-// is possible); min(disc, -bHalf) >= 0 is a superset of that, and what is skipped is no hit in the
+// is possible): can_hit(); what is skipped is no hit in the
 // reference either (disc < 0: ray.cl:78; bHalf >= 0: t <= 0).  count4 is a multiple of 4; the chunk is
 // padded with spheres of r^2 = -inf, whose disc is -inf.
 PT_DEV void scan_chunk(const float4 *buf, int count4, int base, f3 o, f3 d, float a, uint32_t &best, uint32_t &prev, int &idx, float &tiny) {
@@ -239,13 +246,12 @@ PT_DEV void scan_chunk(const float4 *buf, int count4, int base, f3 o, f3 d, floa
 		sphere_disc(g1, o, d, a, b1, d1);
 		sphere_disc(g2, o, d, a, b2, d2);
 		sphere_disc(g3, o, d, a, b3, d3);
-		const float m0 = fminf(d0, -b0), m1 = fminf(d1, -b1), m2 = fminf(d2, -b2), m3 = fminf(d3, -b3);
-		const float m = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
-		if(__builtin_amdgcn_ballot_w64(m >= 0.0f) != 0) {
-			if(__builtin_amdgcn_ballot_w64(m0 >= 0.0f) != 0) candidate_update(b0, d0, base + i, best, prev, idx, tiny);
-			if(__builtin_amdgcn_ballot_w64(m1 >= 0.0f) != 0) candidate_update(b1, d1, base + i + 1, best, prev, idx, tiny);
-			if(__builtin_amdgcn_ballot_w64(m2 >= 0.0f) != 0) candidate_update(b2, d2, base + i + 2, best, prev, idx, tiny);
-			if(__builtin_amdgcn_ballot_w64(m3 >= 0.0f) != 0) candidate_update(b3, d3, base + i + 3, best, prev, idx, tiny);
+		const int m0 = can_hit(b0, d0), m1 = can_hit(b1, d1), m2 = can_hit(b2, d2), m3 = can_hit(b3, d3);
+		if(__builtin_amdgcn_ballot_w64((m0 | m1 | m2 | m3) < 0) != 0) {
+			if(__builtin_amdgcn_ballot_w64(m0 < 0) != 0) candidate_update(b0, d0, base + i, best, prev, idx, tiny);
+			if(__builtin_amdgcn_ballot_w64(m1 < 0) != 0) candidate_update(b1, d1, base + i + 1, best, prev, idx, tiny);
+			if(__builtin_amdgcn_ballot_w64(m2 < 0) != 0) candidate_update(b2, d2, base + i + 2, best, prev, idx, tiny);
+			if(__builtin_amdgcn_ballot_w64(m3 < 0) != 0) candidate_update(b3, d3, base + i + 3, best, prev, idx, tiny);
 		}
 	}
 }
