@@ -4,7 +4,7 @@ spheres; centres and radii on a coarse binary lattice, so that ties and zero dis
 spheres; fuzz 0 and 1; refraction indices on both sides of 1; zero aperture; depth 1), every table size class of the
 kernel choice (1 .. 130 spheres: straight-line scan, scan loop, remainder records, streaming chunks), both kernels,
 1 / 4 / 16 lanes per pixel, one launch / a continued accumulator / three ranks' row bands / the entry point that
-allocates nothing.  The linear float accumulator must equal the oracle's bit for bit and the bounce counts must
+allocates nothing / the opt-in grid.  The linear float accumulator must equal the oracle's bit for bit and the bounce counts must
 agree.  PT_FUZZ_CASES sets the number of scenes (default 300; one-off runs of 30 000 scenes passed on MI355X).
 """
 import os
@@ -101,6 +101,9 @@ def test_random_scenes_are_bit_identical_to_the_oracle(ctx, oracle):
                 elif mode == "bands":                    # three ranks' row bands into one accumulator
                     band = int(rng.choice([1, 3, 8, 100]))
                     bc = sum(ctx.render(sc, W, H, depth, s, rank=r, world=3, band_rows=band, count_bounces=True) for r in (2, 0, 1))
+                elif mode == "plain" and kernel == "stream" and rng.rand() < 0.5:
+                    mode = "grid"                        # the opt-in uniform grid must return the linear scan's hit
+                    bc = ctx.render(sc, W, H, depth, s, count_bounces=True, accel=1)
                 else:
                     bc = ctx.render(sc, W, H, depth, s, count_bounces=True, noalloc=(mode == "noalloc"))
                 img = ctx.image_read()
