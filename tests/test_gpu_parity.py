@@ -340,6 +340,46 @@ def test_u8_epilogue(ctx, oracle):
     assert u8.max() == 255 and u8.min() == 0
 
 
+def test_u8_epilogue_on_every_float_that_matters(ctx, oracle):
+    """pt_to_u8_kernel (gamma 2 as sqrtf, clamp, (int)(x * 255) truncation, include/pt_hip.h pt_image_read_u8) against
+    the oracle's restatement of renderer.c:50-56 (the DOUBLE sqrt narrowed to float) on EVERY float in [0, 1] and a bit
+    above (bit patterns 0 .. 0x3f800100: where the 255 thresholds lie), and on every 4099th pattern of the rest
+    (larger values, negatives, infinities, NaNs: the clamp and the conversion's special cases).  PT_U8_ALL=1 walks all 2^32."""
+    import ctypes as C
+    from concurrent.futures import ThreadPoolExecutor
+    P = 1 << 22                                         # pixels per launch: 3 patterns each
+    # the caller-owned device image comes straight from the HIP runtime the library itself uses (torch would bring a
+    # second copy of the runtime into this process when it is imported after the library)
+    rt = C.CDLL("libamdhip64.so.7")
+    rt.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    rt.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    rt.hipFree.argtypes = [C.c_void_p]
+    dev = C.c_void_p()
+    assert rt.hipMalloc(C.byref(dev), 16 * P) == 0
+
+    def check(pats):
+        n = len(pats) // 3
+        img = np.zeros((n, 4), np.float32)
+        img[:, :3] = pats[:3 * n].view(np.float32).reshape(n, 3)
+        assert rt.hipMemcpy(dev, img.ctypes.data_as(C.c_void_p), img.nbytes, 1) == 0       # hipMemcpyHostToDevice
+        u8 = ctx.image_read_u8(d_image=dev, width=n, height=1).reshape(n, 3)
+        parts = np.array_split(np.arange(n), 16)
+        with ThreadPoolExecutor(16) as ex:
+            want = list(ex.map(lambda ix: oracle.postprocess(img[ix[0]:ix[-1] + 1]), [ix for ix in parts if len(ix)]))
+        want = np.concatenate(want)
+        bad = np.nonzero((u8 != want).any(axis=1))[0]
+        assert len(bad) == 0, "pixel values %r: HIP %r, oracle %r" % (img[bad[0], :3], u8[bad[0]], want[bad[0]])
+
+    everything = os.environ.get("PT_U8_ALL") == "1"
+    hi = (1 << 32) if everything else 0x3f800100
+    for start in range(0, hi, 3 * P):
+        check(np.arange(start, min(start + 3 * P, hi), dtype=np.uint64).astype(np.uint32))
+    if not everything:
+        rest = np.arange(0x3f800100, 1 << 32, 4099, dtype=np.uint64).astype(np.uint32)
+        check(rest[:len(rest) // 3 * 3])
+    assert rt.hipFree(dev) == 0
+
+
 def test_error_paths(ctx):
     sc = scenes.main_lua_frame(0)
     ctx.scene_upload(sc["spheres"])
