@@ -433,6 +433,27 @@ def test_headline_frame_at_its_full_sample_count(ctx, oracle):
     assert np.array_equal(bits(img2[..., :3]), bits(img[..., :3]))
 
 
+@pytest.mark.skipif(os.environ.get("PT_FULL_FRAME") != "1", reason="5 minutes of CPU: set PT_FULL_FRAME=1 (one-off runs recorded in DESIGN.md section 2)")
+def test_headline_frame_every_pixel(ctx, oracle):
+    """The WHOLE headline frame (1920x1080, 256 spp, depth 50: 5.3e8 samples) against the x86 build of the reference
+    kernel itself (oracle/_ref strict build; the oracle restatement where that library is absent), bit for bit."""
+    import time
+    import oracle_lib
+    chk = oracle_lib.load_ref("strict") if oracle_lib.have_ref("strict") else oracle
+    sc = scenes.main_lua_frame(0)
+    W, H, spp = 1920, 1080, 256
+    s = seedmod.glibc_rand_stream(spp)
+    img = hip.render_scene(ctx, sc, W, H, 50, s)
+    t0 = time.time()
+    step = 30
+    for r0 in range(0, H, step):
+        r1 = min(H, r0 + step)
+        want = chk.render(sc, W, H, 50, s, id_begin=r0 * W, id_end=r1 * W, nthreads=16)
+        assert np.array_equal(bits(img[r0:r1, :, :3]), bits(want[r0:r1, :, :3])), "rows %d..%d: %s" % (
+            r0, r1, mismatch_report(img[r0:r1, :, :3].reshape(-1, 3), want[r0:r1, :, :3].reshape(-1, 3)))
+        print("rows %d..%d of %d identical to %s (%.0f s)" % (r0, r1, H, os.path.basename(chk.path), time.time() - t0), flush=True)
+
+
 def test_config3_hundred_thousand_spheres_at_1080p(ctx, oracle):
     """BASELINE config 3 at its largest table AND its full image size: 10^5 spheres, 1920x1080, 1 spp.  The oracle needs
     ~5 ms per path here, so segments of pixels are compared (bit for bit), spread over the image."""
