@@ -433,22 +433,28 @@ def test_headline_frame_at_its_full_sample_count(ctx, oracle):
     assert np.array_equal(bits(img2[..., :3]), bits(img[..., :3]))
 
 
-@pytest.mark.skipif(os.environ.get("PT_FULL_FRAME") != "1", reason="5 minutes of CPU: set PT_FULL_FRAME=1 (one-off runs recorded in DESIGN.md section 2)")
+FULL = os.environ.get("PT_FULL_FRAME", "")
+
+
+@pytest.mark.skipif(FULL not in ("1", "headline", "lattice", "dense10k"),
+                    reason="5-10 minutes of CPU: set PT_FULL_FRAME=headline|lattice|dense10k (one-off runs recorded in DESIGN.md section 2)")
 def test_headline_frame_every_pixel(ctx, oracle):
-    """The WHOLE headline frame (1920x1080, 256 spp, depth 50: 5.3e8 samples) against the x86 build of the reference
-    kernel itself (oracle/_ref strict build; the oracle restatement where that library is absent), bit for bit."""
+    """The WHOLE frame of a BASELINE config at its full sample count — headline: frame-0 scene, 1920x1080, 256 spp, depth 50
+    (5.3e8 samples); lattice: config 5, 64 spp, depth 32; dense10k: config 3, 10^4 spheres, 64 spp — against the x86 build
+    of the reference kernel itself (oracle/_ref strict build; the oracle restatement where that library is absent), bit for bit."""
     import time
     import oracle_lib
     chk = oracle_lib.load_ref("strict") if oracle_lib.have_ref("strict") else oracle
-    sc = scenes.main_lua_frame(0)
-    W, H, spp = 1920, 1080, 256
+    sc, spp, depth = {"lattice": (scenes.glass_lattice(), 64, 32), "dense10k": (scenes.dense_random(10000), 64, 50)}.get(
+        FULL, (scenes.main_lua_frame(0), 256, 50))
+    W, H = 1920, 1080
     s = seedmod.glibc_rand_stream(spp)
-    img = hip.render_scene(ctx, sc, W, H, 50, s)
+    img = hip.render_scene(ctx, sc, W, H, depth, s)
     t0 = time.time()
     step = 30
-    for r0 in range(0, H, step):
+    for r0 in range(int(os.environ.get("PT_FULL_FRAME_ROW0", "0")), H, step):      # (a long check can be split over calls)
         r1 = min(H, r0 + step)
-        want = chk.render(sc, W, H, 50, s, id_begin=r0 * W, id_end=r1 * W, nthreads=16)
+        want = chk.render(sc, W, H, depth, s, id_begin=r0 * W, id_end=r1 * W, nthreads=16)
         assert np.array_equal(bits(img[r0:r1, :, :3]), bits(want[r0:r1, :, :3])), "rows %d..%d: %s" % (
             r0, r1, mismatch_report(img[r0:r1, :, :3].reshape(-1, 3), want[r0:r1, :, :3].reshape(-1, 3)))
         print("rows %d..%d of %d identical to %s (%.0f s)" % (r0, r1, H, os.path.basename(chk.path), time.time() - t0), flush=True)
