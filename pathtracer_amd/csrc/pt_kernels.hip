@@ -579,7 +579,7 @@ static int launch_frames(pt_ctx *c, const pt_render_args *a, float4 *img, hipStr
 	{
 		const char *fs = getenv("PT_LANES_PER_PIXEL");      // debugging aid: force 1, 2, 4 or 8
 		int want = 0;
-		if(fs) { int v = atoi(fs); while((1 << want) < v && want < 5) want++; }
+		if(fs) { int v = atoi(fs); while((1 << want) < v && want < 6) want++; }
 		else {
 			while(want < 2 && (2 << want) <= a->n_frames) want++;      // 4 lanes whatever the frame size (4K: 734 -> 727 ms)
 			while(want < 4 && (lp << want) < 64ll * 12 * 8192 && (2 << want) <= a->n_frames) want++;
@@ -592,13 +592,14 @@ static int launch_frames(pt_ctx *c, const pt_render_args *a, float4 *img, hipStr
 		// ordered accumulation, repeated by every lane of a group, gives back), 4 + the last 8 % at 16: see DESIGN.md §4.
 		int want2 = want;
 		const char *tp = getenv("PT_TAIL_PCT");      // debugging aid: share of the pixels in the second tier, 0 = none
-		const int pct = tp ? atoi(tp) : 8;
+		const int pct = tp ? atoi(tp) : want >= 4 ? 5 : 8;
 		const bool floatFrames = (long long)a->first_frame + a->n_frames < (1 << 24);      // as for the first tier
-		// 16 lanes at most, or 32 where the first tier already has 16 (a small launch, e.g. one rank's band of
-		// eight: 21.39 -> 21.2 ms); PT_TAIL_LANES (a debugging aid) overrides the log2 of that limit.
+		// 16 lanes at most, or a whole wave (64) for the last 5 % where the first tier already has 16 (a small launch:
+		// one rank's band of eight 20.23 -> 20.1 ms, main.lua's 640x360x2000 144.7 -> 142.8 ms); PT_TAIL_LANES (a
+		// debugging aid) overrides the log2 of that limit.
 		const char *tl = getenv("PT_TAIL_LANES");
-		const int cap2 = tl ? atoi(tl) : want >= 4 ? 5 : 4;
-		if((!fs || tp) && pct > 0 && floatFrames) while(want2 < cap2 && want2 < 5 && (2 << want2) <= a->n_frames) want2++;
+		const int cap2 = tl ? atoi(tl) : want >= 4 ? 6 : 4;
+		if((!fs || tp) && pct > 0 && floatFrames) while(want2 < cap2 && want2 < 6 && (2 << want2) <= a->n_frames) want2++;
 		long long tier = lp;
 		if(want2 > want) {
 			tier = lp - lp * pct / 100;

@@ -3,7 +3,7 @@ cases the exactness arguments of pathtracer_amd/csrc/pt_render_kernels.h rest on
 spheres; centres and radii on a coarse binary lattice, so that ties and zero discriminants really occur; cameras inside
 spheres; fuzz 0 and 1; refraction indices on both sides of 1; zero aperture; depth 1), every table size class of the
 kernel choice (1 .. 130 spheres: straight-line scan, scan loop, remainder records, streaming chunks), both kernels,
-1 / 4 / 16 lanes per pixel, one launch / a continued accumulator / three ranks' row bands / the entry point that
+1 / 4 / 16 / 64 lanes per pixel, one launch / a continued accumulator / three ranks' row bands / the entry point that
 allocates nothing / the opt-in grid.  The linear float accumulator must equal the oracle's bit for bit and the bounce counts must
 agree.  PT_FUZZ_CASES sets the number of scenes (default 300; a one-off run of 250 000 scenes passed on MI355X).
 """
@@ -90,7 +90,7 @@ def test_random_scenes_are_bit_identical_to_the_oracle(ctx, oracle):
             want, wb = oracle.render(sc, W, H, depth, s, count_bounces=True)
             for kernel in ("lds", "stream"):
                 os.environ["PT_KERNEL"] = kernel
-                os.environ["PT_LANES_PER_PIXEL"] = str(int(rng.choice([1, 4, 16])))
+                os.environ["PT_LANES_PER_PIXEL"] = str(int(rng.choice([1, 4, 16, 64])))
                 mode = str(rng.choice(["plain", "plain", "continued", "bands", "noalloc"]))
                 ctx.scene_upload(sc["spheres"])
                 ctx.image_alloc(W, H)

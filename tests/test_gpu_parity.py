@@ -238,7 +238,7 @@ def test_frames_compose_and_partition(ctx, oracle):
 
 
 def test_sample_interleaved_lanes_are_bit_identical(ctx, oracle):
-    """2, 4 or 8 lanes per pixel (samples k = sub mod S, colours accumulated in order after each round) give
+    """2 ... 64 lanes per pixel (samples k = sub mod S, colours accumulated in order after each round) give
     the bits of 1 lane per pixel: odd sample counts, fewer samples than lanes, continued accumulators."""
     g = np.load(os.path.join(GOLD, "lattice_96x54.npz"))
     sc = {"spheres": g["spheres"], "bg": g["bg"], "cam": g["cam"]}
@@ -248,7 +248,7 @@ def test_sample_interleaved_lanes_are_bit_identical(ctx, oracle):
         ref = {n: hip.render_scene(ctx, sc, 96, 54, 32, stream[:n], count_bounces=True) for n in (1, 3, 8, 13, 40)}
         want = oracle.render(sc, 96, 54, 32, stream[:13])
         assert np.array_equal(bits(ref[13][0][..., :3]), bits(want[..., :3]))
-        for lanes in (2, 4, 8, 16, 32):
+        for lanes in (2, 4, 8, 16, 32, 64):
             os.environ["PT_LANES_PER_PIXEL"] = str(lanes)
             for n in (1, 3, 8, 13, 40):
                 img, bc = hip.render_scene(ctx, sc, 96, 54, 32, stream[:n], count_bounces=True)
@@ -281,7 +281,7 @@ def test_split_running_mean_and_its_fallback(ctx, oracle):
     try:
         for name, sc in cases:
             want = oracle.render(sc, 96, 54, 50, s)
-            for lanes in (4, 16, 32):
+            for lanes in (4, 16, 64):
                 os.environ["PT_LANES_PER_PIXEL"] = str(lanes)
                 img = hip.render_scene(ctx, sc, 96, 54, 50, s)
                 assert np.array_equal(bits(img[..., :3]), bits(want[..., :3])), (name, lanes)
@@ -317,7 +317,7 @@ def test_two_tier_launch_is_bit_identical(ctx, oracle):
             for r in range(3):
                 ctx.render(sc, W, H, 50, s[16:], first_frame=16, rank=r, world=3, band_rows=7)
             assert np.array_equal(bits(ctx.image_read()[..., :3]), bits(ref[..., :3])), pct
-        # a small launch: the first tier already has 16 lanes per pixel, the second 32
+        # a small launch: the first tier already has 16 lanes per pixel, the second a whole wave
         s = seedmod.glibc_rand_stream(64)
         os.environ["PT_TAIL_PCT"] = "0"
         ref, bc = hip.render_scene(ctx, sc, 640, 360, 50, s, count_bounces=True)
