@@ -588,17 +588,18 @@ static int launch_frames(pt_ctx *c, const pt_render_args *a, float4 *img, hipStr
 		p.logS = want;
 		// The tail of the launch: blocks last nFrames / S rounds and the chip drains over about one block time at the
 		// end, so the pixels whose blocks are dispatched last get more lanes each (shorter blocks; bit-identical).
-		// Measured on the headline frame: 4 lanes everywhere 162.3 ms, 8 everywhere 162.4 (what the tail gains the
-		// ordered accumulation, repeated by every lane of a group, gives back), 4 + the last 8 % at 16: see DESIGN.md §4.
+		// Measured on the headline frame: 4 lanes everywhere 162.3 ms, 8 everywhere 162.4, 4 + the last 8 % at 16: 159.6
+		// (before the running mean was split by channel).
 		int want2 = want;
 		const char *tp = getenv("PT_TAIL_PCT");      // debugging aid: share of the pixels in the second tier, 0 = none
-		const int pct = tp ? atoi(tp) : want >= 4 ? 5 : 8;
+		const int pct = tp ? atoi(tp) : want >= 4 ? 5 : 3;
 		const bool floatFrames = (long long)a->first_frame + a->n_frames < (1 << 24);      // as for the first tier
-		// 16 lanes at most, or a whole wave (64) for the last 5 % where the first tier already has 16 (a small launch:
-		// one rank's band of eight 20.23 -> 20.1 ms, main.lua's 640x360x2000 144.7 -> 142.8 ms); PT_TAIL_LANES (a
-		// debugging aid) overrides the log2 of that limit.
+		// A whole wave (64 lanes) per pixel for the last 3 % of a large launch (headline frame: 157.6 ms against 158.2
+		// with 16 lanes for the last 8 %), the last 5 % of a small one whose first tier already has 16 (one rank's
+		// band of eight 20.23 -> 20.1 ms, main.lua's 640x360x2000 144.7 -> 142.8 ms); PT_TAIL_LANES (a debugging
+		// aid) overrides the log2 of the lane limit.
 		const char *tl = getenv("PT_TAIL_LANES");
-		const int cap2 = tl ? atoi(tl) : want >= 4 ? 6 : 4;
+		const int cap2 = tl ? atoi(tl) : 6;
 		if((!fs || tp) && pct > 0 && floatFrames) while(want2 < cap2 && want2 < 6 && (2 << want2) <= a->n_frames) want2++;
 		long long tier = lp;
 		if(want2 > want) {
