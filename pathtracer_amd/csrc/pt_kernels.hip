@@ -615,7 +615,7 @@ static int launch_frames(pt_ctx *c, const pt_render_args *a, float4 *img, hipStr
 	// LDS kernel: trios of the table that hold a sphere much smaller than the largest one get a wave-level "can any
 	// lane hit it" test per sphere before the sqrt/select part (closest_hit_lds); a pure speed heuristic, same image.
 	// The mask has 32 bits: trios beyond the first 32 (tables above 96 spheres, reachable only with PT_KERNEL=lds —
-	// the lock-step kernel is chosen for at most 64) always take the unconditional path: correct, only slower.
+	// the lock-step kernel is chosen for at most 96) always take the unconditional path: correct, only slower.
 	p.trioSkipMask = 0;
 	if(c->hostSpheres && !getenv("PT_NO_TRIO_SKIP")) {
 		float rmax = 0.0f;
@@ -631,9 +631,10 @@ static int launch_frames(pt_ctx *c, const pt_render_args *a, float4 *img, hipStr
 	// scan (the reference's own scene has 9).  Beyond that the persistent streaming kernel wins on open scenes even
 	// where the table would still fit in LDS, because paths end after a few bounces and its lanes never idle (1080p,
 	// 500 random spheres: 40.7 ms lock-step, 7.6 ms streaming).  In a CLOSED scene paths run to the depth limit, no
-	// lane idles, and the lock-step kernel stays ahead up to about a hundred spheres (39 spheres in the box: 72 vs
-	// 97 ms; 137: 58 vs 55 ms; 355: 175 vs 117 ms): it is chosen up to PT_LOCKSTEP_MAX_CLOSED when rays from the
-	// camera in all 26 axis and diagonal directions hit something.  Either kernel gives the same image.
+	// lane idles, and the lock-step kernel stays ahead up to about 130 spheres (glass lattices in the box at 32 spp,
+	// depth 32: 39 spheres 31.9 vs 46.7 ms; 72: 54.7 vs 70.4; 133: 103.3 vs 106.1; 224: 189 vs 155; 351: 309 vs 234):
+	// it is chosen up to PT_LOCKSTEP_MAX_CLOSED when rays from the camera in all 26 axis and diagonal directions hit
+	// something.  Either kernel gives the same image.
 	const char *force = getenv("PT_KERNEL");      // debugging aid: "stream" or "lds" overrides the choice
 	la.kernel = c->nSpheres <= PT_LOCKSTEP_MAX_SPHERES ? PT_K_LDS : PT_K_STREAM;
 	if(la.kernel == PT_K_STREAM && c->nSpheres <= PT_LOCKSTEP_MAX_CLOSED && camera_is_enclosed(c, a->cam_pos)) la.kernel = PT_K_LDS;

@@ -11,7 +11,7 @@
 // ---------------------------------------------------------------------------------------
 #define PT_LDS_MAX_SPHERES 512       // what the lock-step kernel can hold: 27 KB of LDS per 256-thread block (PT_KERNEL=lds)
 #define PT_LOCKSTEP_MAX_SPHERES 16   // what it is chosen for (pt_render) ...
-#define PT_LOCKSTEP_MAX_CLOSED 64    // ... and up to here when the camera sits in a closed scene (long paths, no idle lanes)
+#define PT_LOCKSTEP_MAX_CLOSED 96    // ... and up to here when the camera sits in a closed scene (long paths, no idle lanes); 96 = what trioSkipMask covers
 
 struct KParams {
 	int W, H, maxDepth, n;

@@ -567,6 +567,25 @@ def test_config4_one_rank_at_its_full_sample_count(ctx, oracle):
     assert not img[8 * 4:8 * 11].any()             # bands of ranks 4..7, 0..2: still the cleared accumulator
 
 
+@pytest.mark.parametrize("k", [4, 5])
+def test_larger_closed_scenes(ctx, oracle, k):
+    """Glass lattices of 4^3 and 5^3 spheres in the closed box (72 and 133 spheres with the walls, light and mirror): the
+    first is rendered by the lock-step kernel's scan loop (pt_render picks it up to 96 spheres in a closed scene; the
+    small-sphere mask is walked as runs of trios), the second by the streaming kernel; forced the other way round they
+    must give the same bits."""
+    sc = scenes.glass_lattice(k)
+    s = seedmod.glibc_rand_stream(6)
+    want, wb = oracle.render(sc, 96, 54, 32, s, count_bounces=True)
+    try:
+        for kernel in (None, "lds", "stream"):
+            if kernel:
+                os.environ["PT_KERNEL"] = kernel
+            img, bc = hip.render_scene(ctx, sc, 96, 54, 32, s, count_bounces=True)
+            assert np.array_equal(bits(img[..., :3]), bits(want[..., :3])) and bc == wb, (k, kernel)
+    finally:
+        os.environ.pop("PT_KERNEL", None)
+
+
 def test_config5_and_config3_at_their_full_sample_counts(ctx, oracle):
     """BASELINE config 5 (glass lattice, depth 32, 1080p, 64 spp) and config 3 (10^4 random spheres, 1080p, 64 spp) as
     DESIGN.md section 6 times them: a row / segments of the frame against the oracle at the full sample count."""

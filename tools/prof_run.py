@@ -9,7 +9,9 @@ from pathtracer_amd import hip, scenes, seeds as seedmod
 SCENES = {
     "frame0": lambda: scenes.main_lua_frame(0),
     "lattice": scenes.glass_lattice,
+    "lattice4": lambda: scenes.glass_lattice(4),
     "lattice5": lambda: scenes.glass_lattice(5),
+    "lattice6": lambda: scenes.glass_lattice(6),
     "lattice7": lambda: scenes.glass_lattice(7),
     "dense10k": lambda: scenes.dense_random(10000),
     "dense100k": lambda: scenes.dense_random(100000),
