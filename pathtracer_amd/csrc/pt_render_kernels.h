@@ -378,9 +378,11 @@ PT_DEV void scan_trio(uint32_t addr, bool skipBit, f3 o, f3 d, float a, uint32_t
 	sphere_disc(g1, o, d, a, b1, d1);
 	sphere_disc(g2, o, d, a, b2, d2);
 	if(SKIP && skipBit) {
-		if(wave_can_hit(d0, b0)) candidate_update(b0, d0, ii.x, best, prev, idx, tiny);
-		if(wave_can_hit(d1, b1)) candidate_update(b1, d1, ii.y, best, prev, idx, tiny);
-		if(wave_can_hit(d2, b2)) candidate_update(b2, d2, ii.z, best, prev, idx, tiny);
+		// (the empty asm keeps the compiler from flattening the branch into "compute the root anyway and select": it
+		// did that to the relaxed build's short update, 65.9 -> 68.5 ms on the 39-sphere lattice)
+		if(wave_can_hit(d0, b0)) { asm volatile(""); candidate_update(b0, d0, ii.x, best, prev, idx, tiny); }
+		if(wave_can_hit(d1, b1)) { asm volatile(""); candidate_update(b1, d1, ii.y, best, prev, idx, tiny); }
+		if(wave_can_hit(d2, b2)) { asm volatile(""); candidate_update(b2, d2, ii.z, best, prev, idx, tiny); }
 	} else {
 		track_tiny2(d0, d1, tiny);
 		track_tiny(d2, tiny);
