@@ -630,7 +630,7 @@ static int launch_frames(pt_ctx *c, const pt_render_args *a, float4 *img, hipStr
 	// Up to PT_LOCKSTEP_MAX_SPHERES spheres: the lock-step kernel with the whole table in LDS and a branch-free
 	// scan (the reference's own scene has 9).  Beyond that the persistent streaming kernel wins on open scenes even
 	// where the table would still fit in LDS, because paths end after a few bounces and its lanes never idle (1080p,
-	// 500 random spheres: 40.7 ms lock-step, 7.6 ms streaming).  In a CLOSED scene paths run to the depth limit, no
+	// 64 spp, random spheres under a sky: 12 spheres 2.2 vs 2.2 ms, 16: 4.0 vs 3.2, 32: 7.0 vs 4.3, 100: 24 vs 7.8).  In a CLOSED scene paths run to the depth limit, no
 	// lane idles, and the lock-step kernel stays ahead up to about 130 spheres (glass lattices in the box at 32 spp,
 	// depth 32: 39 spheres 31.9 vs 46.7 ms; 72: 54.7 vs 70.4; 133: 103.3 vs 106.1; 224: 189 vs 155; 351: 309 vs 234):
 	// it is chosen up to PT_LOCKSTEP_MAX_CLOSED when rays from the camera in all 26 axis and diagonal directions hit

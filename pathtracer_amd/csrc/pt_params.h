@@ -10,7 +10,7 @@
 // value too, src/c/renderer.c:160-162)
 // ---------------------------------------------------------------------------------------
 #define PT_LDS_MAX_SPHERES 512       // what the lock-step kernel can hold: 27 KB of LDS per 256-thread block (PT_KERNEL=lds)
-#define PT_LOCKSTEP_MAX_SPHERES 16   // what it is chosen for (pt_render) ...
+#define PT_LOCKSTEP_MAX_SPHERES 12   // what it is chosen for (pt_render) whatever the scene ...
 #define PT_LOCKSTEP_MAX_CLOSED 96    // ... and up to here when the camera sits in a closed scene (long paths, no idle lanes); 96 = what trioSkipMask covers
 
 struct KParams {

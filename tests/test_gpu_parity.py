@@ -605,7 +605,7 @@ def test_config5_and_config3_at_their_full_sample_counts(ctx, oracle):
 @pytest.mark.parametrize("kernel", ["lds", "stream"])
 @pytest.mark.parametrize("name", sorted(n for n in CASES if not n.startswith(("dense3000", "dense513", "empty"))))
 def test_both_kernels_on_every_small_fixture(ctx, kernel, name):
-    """The kernel choice is a matter of speed only: the lock-step kernel (default up to 16 spheres) and the persistent
+    """The kernel choice is a matter of speed only: the lock-step kernel (default up to 12 spheres, 96 in a closed scene) and the persistent
     streaming kernel (default beyond) must both reproduce the strict reference fixture on every scene either can hold
     (depth 0 and 1, the stuck RNG of pixel 0, duplicates and ties included)."""
     g = np.load(os.path.join(GOLD, name + ".npz"))

@@ -19,6 +19,8 @@ SCENES = {
     "dense500": lambda: scenes.dense_random(500),
     "dense100": lambda: scenes.dense_random(100),
 }
+for _n in (12, 16, 24, 32, 48, 64):      # small open scenes: where the kernel choice of pt_render switches
+    SCENES["dense%d" % _n] = (lambda n: lambda: scenes.dense_random(n))(_n)
 
 
 def main():
