@@ -614,14 +614,14 @@ static int launch_frames(pt_ctx *c, const pt_render_args *a, float4 *img, hipStr
 	}
 	// LDS kernel: trios of the table that hold a sphere much smaller than the largest one get a wave-level "can any
 	// lane hit it" test per sphere before the sqrt/select part (closest_hit_lds); a pure speed heuristic, same image.
-	// The mask has 32 bits: trios beyond the first 32 (tables above 96 spheres, reachable only with PT_KERNEL=lds —
-	// the lock-step kernel is chosen for at most 96) always take the unconditional path: correct, only slower.
+	// The mask has 64 bits: trios beyond the first 64 (tables above 192 spheres, reachable only with PT_KERNEL=lds)
+	// always take the unconditional path: correct, only slower.
 	p.trioSkipMask = 0;
 	if(c->hostSpheres && !getenv("PT_NO_TRIO_SKIP")) {
 		float rmax = 0.0f;
 		for(int i = 0; i < c->nSpheres; i++) rmax = fmaxf(rmax, fabsf(c->hostSpheres[i].w));
-		for(int i = 0; i < c->nSpheres && i < 96 && i / 3 < c->nSpheres / 3; i++)
-			if(fabsf(c->hostSpheres[i].w) < rmax * 0.125f) p.trioSkipMask |= 1u << (i / 3);
+		for(int i = 0; i < c->nSpheres && i < 192 && i / 3 < c->nSpheres / 3; i++)
+			if(fabsf(c->hostSpheres[i].w) < rmax * 0.125f) p.trioSkipMask |= 1ull << (i / 3);
 	}
 	LaunchArgs la;
 	la.image = img; la.p = p; la.sc = sc; la.seedmul = rs.seedmul; la.bounceCounter = rs.counter; la.queue = rs.queue;
@@ -631,8 +631,8 @@ static int launch_frames(pt_ctx *c, const pt_render_args *a, float4 *img, hipStr
 	// scan (the reference's own scene has 9).  Beyond that the persistent streaming kernel wins on open scenes even
 	// where the table would still fit in LDS, because paths end after a few bounces and its lanes never idle (1080p,
 	// 64 spp, random spheres under a sky: 12 spheres 2.2 vs 2.2 ms, 16: 4.0 vs 3.2, 32: 7.0 vs 4.3, 100: 24 vs 7.8).  In a CLOSED scene paths run to the depth limit, no
-	// lane idles, and the lock-step kernel stays ahead up to about 130 spheres (glass lattices in the box at 32 spp,
-	// depth 32: 39 spheres 31.9 vs 46.7 ms; 72: 54.7 vs 70.4; 133: 103.3 vs 106.1; 224: 189 vs 155; 351: 309 vs 234):
+	// lane idles, and the lock-step kernel stays ahead up to about 190 spheres (glass lattices in the box at 32 spp,
+	// depth 32: 39 spheres 31.7 vs 45.9 ms; 72: 54.7 vs 69.3; 133: 92.5 vs 106.4; 224: 158 vs 149; 351: 274 vs 232):
 	// it is chosen up to PT_LOCKSTEP_MAX_CLOSED when rays from the camera in all 26 axis and diagonal directions hit
 	// something.  Either kernel gives the same image.
 	const char *force = getenv("PT_KERNEL");      // debugging aid: "stream" or "lds" overrides the choice

@@ -11,7 +11,7 @@
 // ---------------------------------------------------------------------------------------
 #define PT_LDS_MAX_SPHERES 512       // what the lock-step kernel can hold: 27 KB of LDS per 256-thread block (PT_KERNEL=lds)
 #define PT_LOCKSTEP_MAX_SPHERES 12   // what it is chosen for (pt_render) whatever the scene ...
-#define PT_LOCKSTEP_MAX_CLOSED 96    // ... and up to here when the camera sits in a closed scene (long paths, no idle lanes); 96 = what trioSkipMask covers
+#define PT_LOCKSTEP_MAX_CLOSED 160   // ... and up to here when the camera sits in a closed scene (long paths, no idle lanes)
 
 struct KParams {
 	int W, H, maxDepth, n;
@@ -24,7 +24,7 @@ struct KParams {
 	int localPixels;                    // pixels of this rank
 	int logS;                           // LDS kernel: 2^logS lanes share a pixel (sample-interleaved)
 	int logS2, tierPixels, tierThreads; // LDS kernel: pixels from tierPixels on (threads from tierThreads on) use 2^logS2 lanes
-	unsigned trioSkipMask;              // LDS kernel: bit t = trio t of the table holds a small sphere (closest_hit_lds)
+	unsigned long long trioSkipMask;    // LDS kernel: bit t = trio t of the table holds a small sphere (closest_hit_lds)
 };
 
 // Device scene tables (SoA).  geom[i] = {cx, cy, cz, r*r}; matA[i] = {colr, colg, colb, type bits};

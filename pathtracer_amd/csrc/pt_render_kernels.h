@@ -398,7 +398,7 @@ PT_DEV void scan_trio(uint32_t addr, bool skipBit, f3 o, f3 d, float a, uint32_t
 // reference's nine-sphere scene: 165.9 -> 162 ms).  NT == 0: any table; MASK < 0 is then -1 (small-sphere tests by the
 // run-time mask) or -2 (none).
 template <int NT, int MASK>
-PT_DEV Hit closest_hit_lds(uint32_t base, int n, unsigned skipMask, f3 o, f3 d, float a, float ya) {
+PT_DEV Hit closest_hit_lds(uint32_t base, int n, unsigned long long skipMask, f3 o, f3 d, float a, float ya) {
 	uint32_t best = KEY_NONE, prev = KEY_NONE;
 	float tiny = scan_tiny_init(a);
 	int idx = 0;
@@ -406,7 +406,7 @@ PT_DEV Hit closest_hit_lds(uint32_t base, int n, unsigned skipMask, f3 o, f3 d, 
 	int i = 0;
 	constexpr bool SKIP = NT > 0 ? MASK != 0 : MASK == -1;
 	if(NT > 0) {
-		skipMask = (unsigned)MASK;      // a compile-time constant from here on
+		skipMask = (unsigned long long)MASK;      // a compile-time constant from here on
 #pragma unroll
 		for(int t = 0; t < NT; t++) scan_trio<SKIP>(base + PT_TRIO_BYTES * t, SKIP && ((skipMask >> t) & 1u), o, d, a, best, prev, idx, tiny);
 		i = n;
@@ -415,16 +415,16 @@ PT_DEV Hit closest_hit_lds(uint32_t base, int n, unsigned skipMask, f3 o, f3 d, 
 		// merging them (register copies at every trio): 39-sphere lattice 68.75 -> 64.0 ms
 		int left = n / 3;
 		while(left > 0) {
-			int run = skipMask ? __builtin_ctz(skipMask) : 32;                 // trios without a small sphere
+			int run = skipMask ? __builtin_ctzll(skipMask) : 64;               // trios without a small sphere
 			run = run < left ? run : left;
 			for(int j = 0; j < run; j++, addr += PT_TRIO_BYTES) scan_trio<false>(addr, false, o, d, a, best, prev, idx, tiny);
 			left -= run;
-			skipMask = run < 32 ? skipMask >> run : 0u;
-			run = ~skipMask ? __builtin_ctz(~skipMask) : 32;                      // trios with one
+			skipMask = run < 64 ? skipMask >> run : 0ull;
+			run = ~skipMask ? __builtin_ctzll(~skipMask) : 64;                    // trios with one
 			run = run < left ? run : left;
 			for(int j = 0; j < run; j++, addr += PT_TRIO_BYTES) scan_trio<true>(addr, true, o, d, a, best, prev, idx, tiny);
 			left -= run;
-			skipMask = run < 32 ? skipMask >> run : 0u;
+			skipMask = run < 64 ? skipMask >> run : 0ull;
 		}
 		i = 3 * (n / 3);
 	} else {
@@ -839,7 +839,7 @@ void launch_render(const LaunchArgs &la) {
 			{pt_render_lds_kernel<true, 3, 0>, pt_render_lds_kernel<true, 3, 1>, pt_render_lds_kernel<true, 3, 2>, pt_render_lds_kernel<true, 3, 3>,
 			 pt_render_lds_kernel<true, 3, 4>, pt_render_lds_kernel<true, 3, 5>, pt_render_lds_kernel<true, 3, 6>, pt_render_lds_kernel<true, 3, 7>}};
 		kern_t k;
-		if(la.p.n == 9 && !la.genericScan) k = nine[la.count ? 1 : 0][la.p.trioSkipMask & 7u];
+		if(la.p.n == 9 && !la.genericScan) k = nine[la.count ? 1 : 0][(unsigned)(la.p.trioSkipMask & 7u)];
 		else if(la.p.trioSkipMask) k = la.count ? pt_render_lds_kernel<true, 0, -1> : pt_render_lds_kernel<false, 0, -1>;
 		else k = la.count ? pt_render_lds_kernel<true, 0, -2> : pt_render_lds_kernel<false, 0, -2>;
 		hipLaunchKernelGGL(k, grid, block, la.ldsBytes, la.stream, la.image, la.p, la.sc, la.seedmul, la.bounceCounter);

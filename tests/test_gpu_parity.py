@@ -567,12 +567,12 @@ def test_config4_one_rank_at_its_full_sample_count(ctx, oracle):
     assert not img[8 * 4:8 * 11].any()             # bands of ranks 4..7, 0..2: still the cleared accumulator
 
 
-@pytest.mark.parametrize("k", [4, 5])
+@pytest.mark.parametrize("k", [4, 5, 6])
 def test_larger_closed_scenes(ctx, oracle, k):
-    """Glass lattices of 4^3 and 5^3 spheres in the closed box (72 and 133 spheres with the walls, light and mirror): the
-    first is rendered by the lock-step kernel's scan loop (pt_render picks it up to 96 spheres in a closed scene; the
-    small-sphere mask is walked as runs of trios), the second by the streaming kernel; forced the other way round they
-    must give the same bits."""
+    """Glass lattices of 4^3, 5^3 and 6^3 spheres in the closed box (72, 133 and 224 spheres with the walls, light and
+    mirror): the first two are rendered by the lock-step kernel's scan loop (pt_render picks it up to 160 spheres in a
+    closed scene; the small-sphere mask, 64 trios wide, is walked as runs of trios), the third by the streaming kernel;
+    forced the other way round they must give the same bits."""
     sc = scenes.glass_lattice(k)
     s = seedmod.glibc_rand_stream(6)
     want, wb = oracle.render(sc, 96, 54, 32, s, count_bounces=True)
@@ -605,7 +605,7 @@ def test_config5_and_config3_at_their_full_sample_counts(ctx, oracle):
 @pytest.mark.parametrize("kernel", ["lds", "stream"])
 @pytest.mark.parametrize("name", sorted(n for n in CASES if not n.startswith(("dense3000", "dense513", "empty"))))
 def test_both_kernels_on_every_small_fixture(ctx, kernel, name):
-    """The kernel choice is a matter of speed only: the lock-step kernel (default up to 12 spheres, 96 in a closed scene) and the persistent
+    """The kernel choice is a matter of speed only: the lock-step kernel (default up to 12 spheres, 160 in a closed scene) and the persistent
     streaming kernel (default beyond) must both reproduce the strict reference fixture on every scene either can hold
     (depth 0 and 1, the stuck RNG of pixel 0, duplicates and ties included)."""
     g = np.load(os.path.join(GOLD, name + ".npz"))
