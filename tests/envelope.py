@@ -39,9 +39,29 @@ ENVELOPE_TOL = {
     "env_lattice_256x144": dict(share=0.9845, psnr=22.0, mean=0.002),
 }
 #   any scene, any size: flips come from near-grazing ray-sphere tests, so the budget counts TESTS (bounce-loop
-#   iterations x spheres, both known exactly): between legal reference builds 4e-7 (the reference's scene) to 3.8e-6
-#   (10^4 random spheres) of the tests flip a pixel; stated: at most 2 + 6e-6 * tests pixels farther than 1e-4
-FLIPS_PER_TEST = 6e-6
+#   iterations x spheres, both known exactly).  Measured against the REFERENCE KERNEL ITSELF on MI355X (round 3,
+#   profiles/r03_gpuref_distances.md, tests/golden/gpuref_*.npz): 3.2e-7 .. 5e-7 of the tests flip a pixel on the
+#   reference's own scene (3.3e-7 on all of the 1080p x 256 spp headline frame), 1.1e-6 .. 1.2e-6 in the glass lattice
+#   (1.1e-6 on the 1080p x 64 spp frame), 0.8e-6 .. 2.3e-6 among 500 .. 3000 random spheres, for the strict AND the
+#   relaxed HIP build alike; the x86 builds of the reference sit at the same distances from it.
+#   Stated: at most 2 + 3e-6 * tests pixels farther than 1e-4 (round 2 stated 6e-6 from the x86 envelope alone).
+FLIPS_PER_TEST = 3e-6
+
+# ---- the pin (round 3): the reference kernel compiled for gfx950 with ROCm's own OpenCL builtins, run on MI355X ------
+# tests/golden/gpuref_<case>.npz (tools/make_gpuref_golden.py).  Measured distance of the HIP builds (strict / relaxed)
+# from it on the envelope cases: share within 1e-4 0.99768 / 0.99776, 0.99753 / 0.99816, 0.98896 / 0.98853; PSNR of the
+# 8-bit image 33.75 / 33.81, 50.47 / 55.21, 24.15 / 23.88 dB; image means within 0.03 %.  Stated (a quarter more
+# off-pixels than measured, 0.7 dB):
+GPUREF_TOL = {
+    "env_frame0_256": dict(share=0.9970, psnr=33.0, mean=0.002),
+    "env_dense500_256x144": dict(share=0.9968, psnr=49.5, mean=0.002),
+    "env_lattice_256x144": dict(share=0.9860, psnr=23.1, mean=0.002),
+}
+# cases at the edges of the float format (denormal discriminants, overflow to inf): -cl-fast-relaxed-math implies
+# -cl-finite-math-only and lets the runtime flush or approximate there, so the reference's own GPU output is not a
+# target on them (gpuref with and without the relaxed flags disagree with each other on metal_fuzz70)
+def float_format_edge(name):
+    return "_scale_" in name or "fuzz70" in name
 
 
 def off_pixel_budget(bounce_iterations, n_spheres):
@@ -52,9 +72,10 @@ def off_pixels(a, b, eps=1e-4):
     return int((np.abs(np.asarray(a, np.float32) - np.asarray(b, np.float32)).max(axis=-1) > eps).sum())
 
 
-def check_against_member(name, img_rgb, img_u8, member_rgb, member_u8):
-    """Raises AssertionError unless img is within the stated tolerance of one member of the envelope."""
-    tol = ENVELOPE_TOL[name]
+def check_against_member(name, img_rgb, img_u8, member_rgb, member_u8, tol=None):
+    """Raises AssertionError unless img is within the stated tolerance of one member of the envelope (tol=GPUREF_TOL[name]:
+    of the reference kernel's own image on MI355X)."""
+    tol = tol or ENVELOPE_TOL[name]
     sh, ps = share_within(img_rgb, member_rgb), psnr_u8(img_u8, member_u8)
     ma, mb = float(np.mean(img_rgb, dtype=np.float64)), float(np.mean(member_rgb, dtype=np.float64))
     assert sh >= tol["share"], "%s: only %.5f of the pixels within 1e-4 (stated: %.4f)" % (name, sh, tol["share"])

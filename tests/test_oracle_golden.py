@@ -110,6 +110,28 @@ def test_oracle_matches_reference_images(oracle, name):
         assert envelope.off_pixels(img[..., :3], g["fast"]) <= envelope.off_pixel_budget(bounces, sc["spheres"].shape[0])
     else:
         assert d.max() <= 1e-5
+    # THE PIN: the reference kernel's own output on MI355X (tests/golden/gpuref_*.npz, frozen on the GPU box by
+    # tools/make_gpuref_golden.py from oracle/_ref/ptref_gfx950.hsaco: the kernel compiled verbatim for gfx950 with the
+    # reference's flags and ROCm's own OpenCL builtins).  The oracle is within the stated tolerance of it.
+    if not envelope.float_format_edge(name):
+        want = np.load(os.path.join(GOLD, "gpuref_%s.npz" % name))["rgb"]
+        off, budget = envelope.off_pixels(img[..., :3], want), envelope.off_pixel_budget(bounces, sc["spheres"].shape[0])
+        assert off <= budget, "oracle: %d pixels farther than 1e-4 from the reference kernel on MI355X (stated %d)" % (off, budget)
+
+
+@pytest.mark.parametrize("name", sorted(envelope.ENVELOPE_CASES))
+def test_reference_kernel_on_mi355x_sits_inside_the_envelope_and_the_oracle_within_its_tolerance(oracle, name):
+    """Round 2 predicted the reference's GPU output from five x86 builds; round 3 measured it.  Every x86 member is
+    within the envelope tolerance of the reference kernel's MI355X image, and the oracle (= the strict member) is within
+    the tighter tolerance restated from the measured distances (envelope.GPUREF_TOL)."""
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    W, H, depth, spp = (int(x) for x in g["size"])
+    want = np.load(os.path.join(GOLD, "gpuref_%s.npz" % name))["rgb"]
+    post = lambda x: oracle.postprocess(np.concatenate([x, np.zeros((H, W, 1), np.float32)], axis=2)).reshape(H, W, 3)
+    want_u8 = post(want)
+    for k in envelope.ENVELOPE_KINDS:
+        envelope.check_against_member(name, g[k], post(g[k]), want, want_u8)
+    envelope.check_against_member(name, g["strict"], post(g["strict"]), want, want_u8, tol=envelope.GPUREF_TOL[name])
 
 
 @pytest.mark.parametrize("name", sorted(envelope.ENVELOPE_CASES))

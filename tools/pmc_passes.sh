@@ -1,6 +1,7 @@
 #!/bin/bash
 # rocprofv3 counter passes (one run per pass: <=8 SQ, <=4 TCC, <=2 GRBM counters each) over
-# tools/prof_run.py.  Usage: tools/pmc_passes.sh <tag> [prof_run args...]; CSVs land in gpurun_out/pmc_<tag>/.
+# tools/prof_run.py (or PT_PMC_PROG=tools/ref_gfx950_time.py).  Usage: tools/pmc_passes.sh <tag> [program args...];
+# CSVs land in gpurun_out/pmc_<tag>/.
 set -u
 tag=$1; shift
 root=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
@@ -26,7 +27,7 @@ i=0
 for p in "${passes[@]}"; do
   i=$((i+1))
   echo "== pass $i: $p"
-  timeout -s KILL 120 rocprofv3 --pmc $p -d "$out/p$i" -o p$i --output-format csv -- python3 "$root/tools/prof_run.py" "$@" > "$out/p$i.log" 2>&1 || { echo "pass $i failed"; tail -5 "$out/p$i.log"; exit 1; }
+  timeout -s KILL 120 rocprofv3 --pmc $p -d "$out/p$i" -o p$i --output-format csv -- python3 "$root/${PT_PMC_PROG:-tools/prof_run.py}" "$@" > "$out/p$i.log" 2>&1 || { echo "pass $i failed"; tail -5 "$out/p$i.log"; exit 1; }
   tail -1 "$out/p$i.log"
 done
 find "$out" -name "*counter_collection.csv" | head
