@@ -10,10 +10,14 @@ region starts; the per-step host->device traffic is the 2 KB seed table.
 N = 1 : python bench.py [--steps K --warmup W]
 N > 1 : python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N
         one process per GPU; the SAME image is cut into 8-row bands dealt round-robin to the ranks
-        (work-item ids stay global, so every pixel is bit-identical to the 1-GPU image), each rank
-        renders its bands into a zeroed full-frame buffer and one RCCL reduce(sum) over xGMI per step
-        combines them on rank 0 — inside the timed region, overlapped with the next step's render
-        (two frame buffers).  Fixed total work: "scaling": "strong".
+        (work-item ids stay global, so every pixel is bit-identical to the 1-GPU image); each rank
+        renders its bands and THE PRODUCT'S combine (pt_combine_bands_rank, include/pt_hip.h — what
+        renderer.c runs as pt_combine_bands) brings them to rank 0 inside the timed region: every rank
+        packs its bands into ONE RCCL message over xGMI, rank 0 unpacks; bytes moved per step = the
+        image x (N-1)/N, nothing is zero-filled.  torch.distributed only carries the communicator id,
+        the barrier and the max-over-ranks timing.  If the communicator cannot be set up on every rank
+        the run falls back to zero-filled frames + one torch reduce(sum) per step and says so in
+        config.combine.  Fixed total work: "scaling": "strong".
 
 Prints ONE JSON line on rank 0.
 """
@@ -109,6 +113,62 @@ def measured_traffic():
     return None, None
 
 
+def extras(ctx, stream, torch, hip, scenes, seedmod, budget_s=60.0):
+    """The other BASELINE configs on this GPU (after the timed loop, rank 0, N = 1): kernel time from HIP events (mean of
+    two warm launches), bounces per sample counted in-kernel, the roofline fraction by the same SURVEY.md §8d formula,
+    and a handful of pixels of each frame checked against the CPU oracle at the full sample count, bit for bit."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+    oracle = oracle_lib.load_oracle()
+    threads = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16") or 16))
+    dev = torch.device("cuda", torch.cuda.current_device())
+    cases = [
+        ("configs[0]: frame-0 scene 256x256 16 spp depth 50", "pt_render_lds_kernel", lambda: scenes.main_lua_frame(0), 256, 256, 16, 50, 1, 0, None),
+        ("configs[2]: 10^4 random spheres 1920x1080 64 spp depth 50, linear scan", "pt_render_stream_kernel", lambda: scenes.dense_random(10000), 1920, 1080, 64, 50, 1, 0, (540 * 1920 + 928, 64)),
+        ("configs[3]: frame-0 scene 3840x2160 1024 spp, rank 3 of 8 (8-row bands)", "pt_render_lds_kernel", lambda: scenes.main_lua_frame(0), 3840, 2160, 1024, 50, 8, 3, ((24 * 8 + 3) * 8 * 3840 + 1900, 8)),
+        ("configs[4]: glass lattice + emitters (39 spheres) 1920x1080 64 spp depth 32", "pt_render_lds_kernel (scan loop)", scenes.glass_lattice, 1920, 1080, 64, 32, 1, 0, (500 * 1920 + 900, 64)),
+    ]
+    from pathtracer_amd import partition
+    out, t_begin = [], time.perf_counter()
+    for label, kernel, factory, W, H, spp, depth, world, rank, probe in cases:
+        if time.perf_counter() - t_begin > budget_s:
+            out.append({"workload": label, "skipped": "time budget of the extras spent"})
+            continue
+        sc = factory()
+        n = sc["spheres"].shape[0]
+        s = seedmod.glibc_rand_stream(spp)
+        ctx.scene_upload(sc["spheres"])
+        frame = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)
+        kw = dict(rank=rank, world=world, band_rows=BAND_ROWS, d_image=frame.data_ptr(), stream=stream, async_=True)
+        bounces = ctx.render(sc, W, H, depth, s, count_bounces=True, **{k: v for k, v in kw.items() if k != "async_"})
+        for fast in (False, True):
+            for _ in range(3):
+                ctx.render(sc, W, H, depth, s, record_timing=True, fast_math=fast, **kw)
+        torch.cuda.synchronize()
+        kt = ctx.kernel_times()
+        ms, fast_ms = float(np.mean(kt[1:3])), float(np.mean(kt[4:6]))
+        ctx.render(sc, W, H, depth, s, **kw)                  # the strict build's frame, for the check below
+        torch.cuda.synchronize()
+        samples = partition.local_pixel_count(W, H, rank, world, BAND_ROWS) * spp
+        bps = bounces / samples
+        fps = flops_per_sample(bps, n)
+        b, cnt = probe if probe else (0, W * H)
+        want = oracle.render(sc, W, H, depth, s, id_begin=b, id_end=b + cnt, nthreads=threads).reshape(-1, 4)[b:b + cnt, :3]
+        got = frame.reshape(-1, 4)[b:b + cnt, :3].cpu().numpy()
+        if not np.array_equal(np.ascontiguousarray(got).view(np.uint32), np.ascontiguousarray(want).view(np.uint32)):
+            raise SystemExit("bench.py extras: %s: pixels %d..%d differ from the oracle" % (label, b, b + cnt))
+        e = {"workload": label, "spheres": int(n), "kernel": kernel,
+             "kernel_ms": ms, "msamples_s": samples / ms / 1e3, "bounces_per_sample": round(bps, 3),
+             "frac": fps * samples / (ms * 1e-3) / 1e12 / PEAK_FP32_VALU_TFLOPS,
+             "fast_math_kernel_ms": fast_ms, "fast_math_frac": fps * samples / (fast_ms * 1e-3) / 1e12 / PEAK_FP32_VALU_TFLOPS,
+             "checked_pixels": int(cnt), "checked": "pixels %d..%d bit-identical to the CPU oracle at %d spp" % (b, b + cnt - 1, spp)}
+        if n >= 1000:
+            e["gtests_s"] = samples * bps * n / (ms * 1e-3) / 1e9      # ray-sphere tests per second (SURVEY.md §8d)
+        out.append(e)
+        del frame
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -117,6 +177,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true", help="skip the oracle check of the benchmarked frame (about 3 s of CPU)")
     ap.add_argument("--no-fast-math", action="store_true", help="skip the extra, untimed measurement of the relaxed-float build")
+    ap.add_argument("--no-extras", action="store_true", help="skip the untimed measurements of the other BASELINE configs (about 20 s)")
+    ap.add_argument("--combine", choices=("product", "torch"), default="product",
+                    help="N > 1: the product's packed RCCL combine (default) or the zero-fill + torch reduce fallback")
     ap.add_argument("--force-dist", action="store_true",
                     help="debug: run the multi-rank code path (process group, zero-fill, RCCL reduce, barrier) even with one rank")
     ap.add_argument("--spp", type=int, default=SPP, help="debug only: any value but %d is not the benchmark" % SPP)
@@ -160,13 +223,37 @@ def main():
     stream = side.cuda_stream
     assert stream != 0
 
+    # N > 1: the product's combine needs one RCCL communicator over the ranks' contexts; torch.distributed carries its id
+    packed = False
+    if multi:
+        ok = 0
+        if args.combine == "product":
+            try:
+                box = [hip.comm_unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(box, src=0)
+                ctx.comm_init_rank(world, rank, box[0])
+                ok = 1
+            except Exception as e:      # library, symbol or communicator trouble on this rank: every rank falls back together
+                print("bench.py: rank %d: product combine unavailable (%s); falling back to torch reduce" % (rank, e), file=sys.stderr, flush=True)
+        agree = torch.tensor([ok], dtype=torch.int32, device=dev)
+        dist.all_reduce(agree, op=dist.ReduceOp.MIN)
+        packed = bool(int(agree[0]) == 1)
+
+    def combine(buf):
+        if packed:
+            ctx.combine_bands_rank(0, BAND_ROWS, d_image=buf.data_ptr(), width=WIDTH, height=HEIGHT, stream=stream)
+            return None
+        return dist.reduce(buf, dst=0, op=dist.ReduceOp.SUM, async_op=True)
+
     def step(count=False):
-        if multi:
+        if multi and not packed:
             frame.zero_()
         bc = ctx.render(scene, WIDTH, HEIGHT, DEPTH, seeds, rank=rank, world=world, band_rows=BAND_ROWS,
                         d_image=frame.data_ptr(), stream=stream, count_bounces=count, async_=True)
         if multi:
-            dist.reduce(frame, dst=0, op=dist.ReduceOp.SUM)
+            w = combine(frame)
+            if w is not None:
+                w.wait()
         return bc
 
     # untimed: bounce-loop iterations of this rank's share (deterministic given the seeds) for the FLOP count
@@ -183,13 +270,14 @@ def main():
         raise SystemExit("bench.py: at most 256 timed steps (size of the C ABI's kernel-timing ring)")
     barrier()
     t0 = time.perf_counter()
-    # N > 1: two frame buffers, so that the RCCL reduce of step k overlaps the render of step k+1 (the reduce is
-    # asynchronous; a buffer is zeroed again only after the reduce that read it has been waited for)
-    frames = [frame, torch.zeros_like(frame)] if multi else [frame]
+    # N > 1, product combine: render -> pack -> one send per rank, all enqueued on this rank's stream; rank 0 receives and
+    # unpacks on its own.  Fallback: two zero-filled frame buffers, so that the torch reduce of step k overlaps the render
+    # of step k+1 (a buffer is zeroed again only after the reduce that read it has been waited for)
+    frames = [frame, torch.zeros_like(frame)] if (multi and not packed) else [frame]
     pending = [None, None]
     for k in range(args.steps):
         buf = frames[k % len(frames)]
-        if multi:
+        if multi and not packed:
             if pending[k % 2] is not None:
                 pending[k % 2].wait()
             buf.zero_()
@@ -197,12 +285,12 @@ def main():
         ctx.render(scene, WIDTH, HEIGHT, DEPTH, seeds, rank=rank, world=world, band_rows=BAND_ROWS,
                    d_image=buf.data_ptr(), stream=stream, async_=True, record_timing=True)
         if multi:
-            pending[k % 2] = dist.reduce(buf, dst=0, op=dist.ReduceOp.SUM, async_op=True)
+            pending[k % 2] = combine(buf)
     for w in pending:
         if w is not None:
             w.wait()
     if multi:
-        frame = frames[(args.steps - 1) % 2]       # the last step's reduced image, checked below
+        frame = frames[(args.steps - 1) % len(frames)]       # the last step's combined image, checked below
     barrier()
     dt = time.perf_counter() - t0
 
@@ -258,7 +346,11 @@ def main():
             "data": "synthetic",
             "config": {"workload": "main.lua frame-0 scene 1920x1080 %d spp depth 50 (BASELINE configs[1])" % spp,
                        "spheres": n_spheres, "seeds": "glibc rand() stream, first %d values" % spp,
-                       "partition": "1 GPU" if world == 1 else "%d-row bands round-robin over %d ranks + RCCL reduce" % (BAND_ROWS, world),
+                       "partition": "1 GPU" if world == 1 else "%d-row bands round-robin over %d ranks" % (BAND_ROWS, world),
+                       "combine": "none (1 GPU)" if not multi else
+                                  ("pt_combine_bands_rank: one packed RCCL message per rank to rank 0, %.1f MB per step in %d messages"
+                                   % (16.0 * WIDTH * HEIGHT * (world - 1) / world / 1e6, world - 1)) if packed else
+                                  "fallback: zero-filled full frames + torch.distributed reduce(sum), %.1f MB per rank per step" % (16.0 * WIDTH * HEIGHT / 1e6),
                        "bounces_per_sample": round(bps, 3),
                        "verified_rows": verified,
                        "verified": ("rows %s of the last timed frame bit-identical to the CPU oracle at %d spp" % (list(VERIFY_ROWS), spp))
@@ -282,6 +374,8 @@ def main():
                                         "1-ulp v_sqrt_f32/v_rcp_f32, as the reference's own -cl-fast-relaxed-math allows; same RNG "
                                         "stream, image within the tolerance of tests/test_gpu_fast_math.py, not bit-identical; "
                                         "kernel time only, not the reported value"}
+        if world == 1 and not multi and not args.no_extras and spp == SPP:
+            out["extras"] = extras(ctx, stream, torch, hip, scenes, seedmod)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene, seedmod.glibc_rand_stream(SPP))
         print(json.dumps(out), flush=True)

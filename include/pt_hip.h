@@ -94,6 +94,12 @@ int pt_ctx_create(int device, pt_ctx **out);
 /* Destroy the context and free its device memory.  Replaces clRelease* (src/c/renderer.c:295-303). */
 int pt_ctx_destroy(pt_ctx *ctx);
 
+/* The PT_* environment switches (PT_MATH, PT_ACCEL, PT_KERNEL, PT_GENERIC_SCAN, PT_NO_TRIO_SKIP, PT_LANES_PER_PIXEL,
+ * PT_TAIL_PCT, PT_TAIL_LANES, PT_COMBINE: opt-ins and debugging aids) are read ONCE, by pt_ctx_create; no render call
+ * reads the environment.  This re-reads them for a context whose process changed them afterwards (the tests do).
+ * No reference counterpart (the reference has no run-time switches). */
+int pt_ctx_reload_env(pt_ctx *ctx);
+
 /* (Re)allocate the context's own accumulator, width*height float4, zero-filled.
  * Replaces clCreateBuffer(imageBuff) in set_image_properties (src/c/renderer.c:103). */
 int pt_image_alloc(pt_ctx *ctx, int width, int height);
@@ -106,6 +112,22 @@ int pt_scene_upload(pt_ctx *ctx, const float *spheres, int n);
  * clSetKernelArg ×7 + clEnqueueNDRangeKernel + clFinish (src/c/renderer.c:159-179,251). */
 int pt_render(pt_ctx *ctx, const pt_render_args *args);
 
+/* Launch geometry pt_render would use for the lock-step kernel on these arguments (width, height, first_frame,
+ * n_frames, rank, world, band_rows; the rest is ignored): lanes per pixel of the two tiers, the tier boundary, the total
+ * thread count (kept below 2^31 — the kernels index threads with a 32-bit int — by giving up the tail tier and then
+ * lanes per pixel on frames above ~3.7e8 pixels per rank) and the number of 256-thread blocks.  Host arithmetic only:
+ * needs no GPU.  No reference counterpart (its NDRange is W*H work-items, src/c/renderer.c:168); for the tests. */
+typedef struct pt_launch_plan {
+	long long local_pixels;       /* pixels of this rank */
+	int lanes_log2;               /* first tier: 2^lanes_log2 lanes per pixel */
+	int tail_lanes_log2;          /* second tier (the pixels dispatched last) */
+	long long tier_pixels;        /* pixels in the first tier */
+	long long tier_threads;       /* threads of the first tier = tier_pixels << lanes_log2 */
+	long long total_threads;      /* < 2^31 */
+	unsigned blocks;
+} pt_launch_plan;
+int pt_plan_launch(const pt_render_args *args, pt_launch_plan *out);
+
 /* pt_render for callers that cannot allocate: code under HIP graph capture, tight serving loops, harnesses that
  * forbid hipMalloc.  NO COUNTERPART IN THE REFERENCE (its host allocates a sphere buffer per render(),
  * src/c/renderer.c:155).  Same arguments, same kernels, same image as pt_render, but the call makes no hipMalloc,
@@ -116,23 +138,50 @@ int pt_render(pt_ctx *ctx, const pt_render_args *args);
  * and the accumulator (args->d_image, or the context's own from pt_image_alloc).
  * Limits, rejected with PT_E_INVALID and a message: n_frames <= PT_NOALLOC_MAX_FRAMES per call (continue with
  * first_frame for more); accel must be 0 (building the grid allocates; PT_ACCEL is ignored here).
- * All contexts on one GPU share that GPU's array: two pt_render_noalloc calls that overlap in time on the same
- * GPU (different streams or threads) race on it.  Calls in sequence are safe; each call re-initialises what it
- * needs (queue head and counter are cleared, the seed table is rewritten). */
+ * All contexts on one GPU share that GPU's array, so calls on one GPU must not overlap in time.  Calls on one stream
+ * are ordered and safe (each call re-initialises what it needs: queue head and counter are cleared, the seed table is
+ * rewritten); a call made while an earlier one is still running on ANOTHER stream of the same GPU is refused with
+ * PT_E_STATE (one event per GPU tracks the last call; calls that replay from a captured graph are not tracked — keep
+ * such graphs on one stream).
+ * Under stream capture (hipStreamBeginCapture on args->stream) only the enqueue-and-return form is legal: async must be
+ * 1 and bounce_count, kernel_ms and record_timing unset — each of those synchronises or records timing events — else
+ * PT_E_INVALID.  What is captured: the seed staging kernel(s), one 256-byte memset for the streaming kernel, the
+ * render kernel.  The seeds are baked into the graph as kernel arguments. */
 #define PT_NOALLOC_MAX_FRAMES 4096
 int pt_render_noalloc(pt_ctx *ctx, const pt_render_args *args);
 
 /* Multi-GPU combine, for one process driving several GPUs (pathtracer_amd/csrc/renderer.c with PT_NUM_GPUS > 1).
  * NO COUNTERPART IN THE REFERENCE (single device, src/c/renderer.c:72); SURVEY.md §8e.  ctxs[i] is rank i of world n:
  * each has rendered its own row bands (pt_render with rank = i, world = n, band_rows) into its context accumulator
- * (pt_image_alloc, same size everywhere).  On return the transfers are ENQUEUED that bring every other rank's bands
- * into ctxs[root]'s accumulator, in place, each band once: one group of RCCL ncclSend / ncclRecv pairs over xGMI, the
- * sends ordered after each rank's render on that rank's stream, the receives on the root's stream — pt_sync(ctxs[root])
- * or pt_image_read*(ctxs[root], ...) waits for them.  Nothing needs to be zero anywhere; bytes moved = the image minus
- * the root's own bands.  librccl is loaded on first use.  n <= 8; the ranks' GPUs must be pairwise distinct — or all
- * the same one (a debugging arrangement: several contexts on one GPU), in which case the bands are device-to-device
- * copies and RCCL is not involved.  Communicators are created once per device list and kept until the process ends. */
+ * (pt_image_alloc, same size everywhere).  On return the work is ENQUEUED that brings every other rank's bands into
+ * ctxs[root]'s accumulator, each band once, as ONE message per peer: the peer packs its bands into a compact staging
+ * buffer (in the order the render kernel numbers its own pixels) on its stream, after its render; one RCCL
+ * ncclSend / ncclRecv pair per peer, all in one group, moves it over that peer's xGMI link; the root unpacks on its
+ * stream — pt_sync(ctxs[root]) or pt_image_read*(ctxs[root], ...) waits for all of it.  Nothing needs to be zero
+ * anywhere; bytes moved = the image minus the root's own bands, in n - 1 messages.  librccl is loaded on first use;
+ * communicators are created once per device list and kept until the process ends.  If RCCL cannot be set up (library,
+ * symbol or communicator creation fails) the same packed buffers travel as peer copies ordered by events, with a line
+ * on stderr (PT_COMBINE=copy asks for that, PT_COMBINE=rccl forbids the fallback).  n <= 8; the ranks' GPUs must be
+ * pairwise distinct — or all the same one (a debugging arrangement: several contexts on one GPU, which cannot be RCCL
+ * peers), in which case the messages are device-to-device copies. */
 int pt_combine_bands(pt_ctx *const *ctxs, int n, int root, int band_rows);
+
+/* Which transport the last pt_combine_bands / pt_combine_bands_rank call on this thread used:
+ * "rccl", "peer-copy", "device-copy", or "none" (one rank).  No reference counterpart. */
+const char *pt_combine_transport(void);
+
+/* The same combine for one process PER GPU (bench.py --gpus N under torch.distributed.run; an MPI-style launcher).
+ * NO COUNTERPART IN THE REFERENCE.  Rank 0 obtains an id with pt_comm_unique_id (ncclGetUniqueId; PT_COMM_ID_BYTES
+ * bytes) and hands it to the other processes by whatever channel the launcher offers; every rank then calls
+ * pt_comm_init_rank (ncclCommInitRank; collective: all ranks must call it) on its context, and after each render
+ * pt_combine_bands_rank: a non-root rank packs its bands of d_image (NULL: the context's accumulator) and sends them
+ * as one message; the root receives one message per peer (one group) and unpacks them into its d_image.  Everything
+ * is enqueued on `stream` (NULL: the context's), ordered after the render that was launched there.  Bytes moved and
+ * message count as pt_combine_bands.  The communicator is destroyed with the context. */
+#define PT_COMM_ID_BYTES 128
+int pt_comm_unique_id(void *id, int bytes);
+int pt_comm_init_rank(pt_ctx *ctx, int world, int rank, const void *id);
+int pt_combine_bands_rank(pt_ctx *ctx, int root, int band_rows, void *d_image, int width, int height, void *stream);
 
 /* Durations (ms) of the render kernels launched with record_timing since the last call, oldest first:
  * waits for those launches, writes up to `cap` values to ms[], stores the count in *n and empties the

@@ -210,6 +210,16 @@ __global__ void pt_selftest_kernel(int op, const uint64_t *a, const uint64_t *b,
 #define PT_SCRATCH_BYTES (PT_SCRATCH_SEEDS_OFF + 8 * PT_NOALLOC_MAX_FRAMES)
 static __device__ __align__(256) unsigned char scratch[PT_SCRATCH_BYTES];
 
+// Calls of pt_render_noalloc on one GPU share that GPU's `scratch`: a call that would overlap an earlier one still
+// running on ANOTHER stream is refused (PT_E_STATE) instead of racing.  One event per GPU, created by the first
+// pt_ctx_create on it (never inside pt_render_noalloc: creating an event allocates), recorded behind every call.
+#define PT_MAX_DEVICES 64
+namespace {
+struct NoallocSlot { hipEvent_t ev; hipStream_t stream; bool armed; };
+NoallocSlot g_noalloc[PT_MAX_DEVICES];
+std::mutex g_noallocLock;
+}
+
 // Host seeds -> the scratch seed table without any staging allocation: up to 256 seeds ride in the kernel
 // arguments (2 KB by value), the kernel folds the sample-uniform 16807 * seed (src/cl/rng.cl:8) and stores them.
 struct SeedChunk { uint64_t v[256]; };
@@ -237,9 +247,49 @@ static int fail(int code, const char *fmt, const char *detail) {
 		}                                                                                      \
 	} while(0)
 
+// The PT_* environment switches (debugging aids and opt-ins), read ONCE per context (pt_ctx_create) and again only
+// when the caller asks (pt_ctx_reload_env): no getenv on the render path.
+struct Switches {
+	int lanesPerPixel;      // PT_LANES_PER_PIXEL: force 1 .. 64 lanes per pixel; -1: chosen by pt_render
+	int tailPct;            // PT_TAIL_PCT: share of the pixels in the second tier; -1: default
+	int tailLanes;          // PT_TAIL_LANES: log2 of the second tier's lane limit; -1: default (6)
+	bool noTrioSkip;        // PT_NO_TRIO_SKIP
+	int kernel;             // PT_KERNEL: 0 chosen by pt_render, 1 "stream", 2 "lds"
+	bool genericScan;       // PT_GENERIC_SCAN
+	int math;               // PT_MATH: 0 pt_render_args.fast_math decides, 1 "fast", 2 "strict"
+	int accel;              // PT_ACCEL: 0 pt_render_args.accel decides, 1 "grid", 2 "none"
+	int combine;            // PT_COMBINE: 0 RCCL, peer copies where it cannot be set up; 1 "copy"; 2 "rccl" (no fallback)
+};
+static Switches read_switches() {
+	Switches w;
+	const char *v;
+	w.lanesPerPixel = (v = getenv("PT_LANES_PER_PIXEL")) ? atoi(v) : -1;
+	w.tailPct = (v = getenv("PT_TAIL_PCT")) ? atoi(v) : -1;
+	w.tailLanes = (v = getenv("PT_TAIL_LANES")) ? atoi(v) : -1;
+	w.noTrioSkip = getenv("PT_NO_TRIO_SKIP") != NULL;
+	v = getenv("PT_KERNEL");
+	w.kernel = v && strcmp(v, "stream") == 0 ? 1 : v && strcmp(v, "lds") == 0 ? 2 : 0;
+	w.genericScan = getenv("PT_GENERIC_SCAN") != NULL;
+	v = getenv("PT_MATH");
+	w.math = v && strcmp(v, "fast") == 0 ? 1 : v && strcmp(v, "strict") == 0 ? 2 : 0;
+	v = getenv("PT_ACCEL");
+	w.accel = v && strcmp(v, "grid") == 0 ? 1 : v && strcmp(v, "none") == 0 ? 2 : 0;
+	v = getenv("PT_COMBINE");
+	w.combine = v && strcmp(v, "copy") == 0 ? 1 : v && strcmp(v, "rccl") == 0 ? 2 : 0;
+	return w;
+}
+
 struct pt_ctx {
 	int device;
 	hipStream_t stream;
+	Switches sw;
+	// derived from the uploaded scene once (pt_scene_upload), not per launch
+	unsigned long long sceneTrioMask;     // trios that hold a sphere under an eighth of the largest radius (closest_hit_lds)
+	float enclosedPos[3]; int enclosedKnown, enclosed;   // camera_is_enclosed() of the last camera position asked about
+	// multi-GPU combine (pt_combine_bands*): packed bands of this rank / of the peers (root), RCCL communicator of a
+	// multi-process job (pt_comm_init_rank)
+	float4 *stage; size_t capStage;
+	void *mpComm; int mpWorld, mpRank;
 	float4 *image; int imgW, imgH;
 	float4 *geom, *matA, *matB; int nSpheres, capSpheres;
 	uint64_t *seedmul; int capSeeds;
@@ -281,6 +331,7 @@ extern "C" int pt_ctx_create(int device, pt_ctx **out) {
 	pt_ctx *c = (pt_ctx *)calloc(1, sizeof(pt_ctx));
 	if(!c) return fail(PT_E_NOMEM, "pt_ctx_create: host allocation failed%s", NULL);
 	c->device = device;
+	c->sw = read_switches();
 	// every step after the calloc: on failure the half-built context is torn down again (pt_ctx_destroy copes with
 	// the members that are still NULL) and the first error is what the caller sees
 	hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
@@ -292,6 +343,10 @@ extern "C" int pt_ctx_create(int device, pt_ctx **out) {
 	for(int i = 0; e == hipSuccess && i < 2 * PT_TIMING_SLOTS; i++) { e = hipEventCreate(&c->ring[i]); what = "hipEventCreate(ring)"; }
 	// this GPU's copy of the no-allocation scratch: its device address, looked up with this device current
 	if(e == hipSuccess) { e = hipGetSymbolAddress((void **)&c->scratchPtr, HIP_SYMBOL(scratch)); what = "hipGetSymbolAddress(scratch)"; }
+	if(e == hipSuccess && device < PT_MAX_DEVICES) {
+		std::lock_guard<std::mutex> lock(g_noallocLock);
+		if(!g_noalloc[device].ev) { e = hipEventCreateWithFlags(&g_noalloc[device].ev, hipEventDisableTiming); what = "hipEventCreate(noalloc)"; }
+	}
 	if(e != hipSuccess) {
 		char msg[256];
 		snprintf(msg, sizeof msg, "%s failed: %s", what, hipGetErrorString(e));
@@ -303,6 +358,14 @@ extern "C" int pt_ctx_create(int device, pt_ctx **out) {
 	return PT_OK;
 }
 
+static void pt_comm_release(pt_ctx *c);
+
+extern "C" int pt_ctx_reload_env(pt_ctx *c) {
+	if(!c) return fail(PT_E_INVALID, "pt_ctx_reload_env: NULL%s", NULL);
+	c->sw = read_switches();
+	return PT_OK;
+}
+
 extern "C" int pt_ctx_destroy(pt_ctx *c) {
 	if(!c) return PT_OK;
 	(void)hipSetDevice(c->device);
@@ -310,7 +373,8 @@ extern "C" int pt_ctx_destroy(pt_ctx *c) {
 	(void)hipFree(c->image); (void)hipFree(c->geom); (void)hipFree(c->matA); (void)hipFree(c->matB);
 	(void)hipFree(c->seedmul); (void)hipFree(c->counter); (void)hipFree(c->queue);
 	(void)hipFree(c->dCellStart); (void)hipFree(c->dItems); (void)hipFree(c->dBig);
-	free(c->hostSpheres); (void)hipFree(c->u8);
+	free(c->hostSpheres); (void)hipFree(c->u8); (void)hipFree(c->stage);
+	if(c->mpComm) pt_comm_release(c);
 	if(c->evStart) (void)hipEventDestroy(c->evStart);
 	if(c->evStop) (void)hipEventDestroy(c->evStop);
 	for(int i = 0; i < 2 * PT_TIMING_SLOTS; i++) if(c->ring[i]) (void)hipEventDestroy(c->ring[i]);
@@ -345,6 +409,8 @@ extern "C" int pt_scene_upload(pt_ctx *c, const float *spheres, int n) {
 	}
 	c->nSpheres = n;
 	c->gridBuilt = false;
+	c->sceneTrioMask = 0;
+	c->enclosedKnown = 0;
 	free(c->hostSpheres); c->hostSpheres = NULL;
 	if(n == 0) return PT_OK;
 	c->hostSpheres = (float4 *)malloc(sizeof(float4) * (size_t)n);
@@ -352,6 +418,16 @@ extern "C" int pt_scene_upload(pt_ctx *c, const float *spheres, int n) {
 	for(int i = 0; i < n; i++) {
 		const float *r = spheres + PT_SPHERE_FLOATS * (size_t)i;
 		c->hostSpheres[i] = make_float4(r[0], r[1], r[2], r[3]);
+	}
+	// LDS kernel: trios of the table that hold a sphere much smaller than the largest one get a wave-level "can any
+	// lane hit it" test per sphere before the sqrt/select part (closest_hit_lds); a pure speed heuristic, same image.
+	// The mask has 64 bits: trios beyond the first 64 (tables above 192 spheres, reachable only with PT_KERNEL=lds)
+	// always take the unconditional path: correct, only slower.
+	{
+		float rmax = 0.0f;
+		for(int i = 0; i < n; i++) rmax = fmaxf(rmax, fabsf(c->hostSpheres[i].w));
+		for(int i = 0; i < n && i < 192 && i / 3 < n / 3; i++)
+			if(fabsf(c->hostSpheres[i].w) < rmax * 0.125f) c->sceneTrioMask |= 1ull << (i / 3);
 	}
 	float4 *h = (float4 *)malloc(sizeof(float4) * 3 * (size_t)n);
 	if(!h) return fail(PT_E_NOMEM, "pt_scene_upload: host allocation failed%s", NULL);
@@ -502,14 +578,13 @@ static int build_grid(pt_ctx *c, hipStream_t st) {
 	return PT_OK;
 }
 
-static int local_rows(int H, int rank, int world, int band) {
-	// rows r with (r / band) % world == rank
-	int rows = 0;
-	int nb = (H + band - 1) / band;
-	for(int b = rank; b < nb; b += world) {
-		int lo = b * band, hi = lo + band < H ? lo + band : H;
-		rows += hi - lo;
-	}
+// rows r with (r / band) % world == rank
+static long long local_rows64(int H, int rank, int world, int band) {
+	const long long nb = ((long long)H + band - 1) / band;          // bands of the image, the last one possibly short
+	if(rank >= nb) return 0;
+	const long long mine = (nb - 1 - rank) / world + 1;               // bands rank, rank + world, ...
+	long long rows = mine * band;
+	if((nb - 1) % world == rank) rows -= nb * band - H;               // this rank owns the short last band
 	return rows;
 }
 
@@ -541,6 +616,72 @@ struct RenderScratch {
 	unsigned int *queue;
 };
 
+// Launch geometry of the lock-step kernel: lanes per pixel for the two tiers of a launch, in 64-bit arithmetic.
+// The kernel indexes threads with a 32-bit int (pt_render_kernels.h), so the total must stay below 2^31: a frame
+// whose tiers would exceed that (above ~3.7e8 pixels per rank with the default tiers) loses the tail tier first and
+// then lanes per pixel; one lane per pixel always fits (pt_image_alloc admits 2^30 pixels).
+struct LaunchPlan { int logS, logS2; long long tierPixels, tierThreads, totalThreads; unsigned blocks; };
+
+static int plan_launch(long long lp, int firstFrame, int nFrames, const Switches &sw, LaunchPlan *out) {
+	// enough lanes per pixel that the launch has about a dozen rounds of the chip's 8192 wave slots, at most 16
+	// (measured: the 1080p headline frame 243 ms at 1 lane per pixel, 231 ms at 4; one rank's eighth of it
+	// 32.9 / 28.6 / 26.1 / 25.0 / 24.4 ms at 1 / 2 / 4 / 8 / 16 lanes, 25.1 ms at 32)
+	int want = 0;
+	const bool forced = sw.lanesPerPixel >= 0;
+	if(forced) { while((1 << want) < sw.lanesPerPixel && want < 6) want++; }
+	else {
+		while(want < 2 && (2 << want) <= nFrames) want++;      // 4 lanes whatever the frame size (4K: 734 -> 727 ms)
+		while(want < 4 && (lp << want) < 64ll * 12 * 8192 && (2 << want) <= nFrames) want++;
+	}
+	const bool floatFrames = (long long)firstFrame + nFrames < (1 << 24);      // the group accumulation counts frames in float
+	if(!floatFrames) want = 0;
+	// The tail of the launch: blocks last nFrames / S rounds and the chip drains over about one block time at the
+	// end, so the pixels whose blocks are dispatched last get more lanes each (shorter blocks; bit-identical).
+	// A whole wave (64 lanes) per pixel for the last 3 % of a large launch (headline frame: 157.6 ms against 158.2
+	// with 16 lanes for the last 8 %, 162.3 without a second tier), the last 5 % of a small one whose first tier
+	// already has 16 (one rank's band of eight 20.23 -> 20.1 ms, main.lua's 640x360x2000 144.7 -> 142.8 ms).
+	// PT_TAIL_PCT / PT_TAIL_LANES (debugging aids) override the share and the log2 of the lane limit.
+	int want2 = want;
+	const int pct = sw.tailPct >= 0 ? sw.tailPct : want >= 4 ? 5 : 3;
+	const int cap2 = sw.tailLanes >= 0 ? sw.tailLanes : 6;
+	if((!forced || sw.tailPct >= 0) && pct > 0 && floatFrames) while(want2 < cap2 && want2 < 6 && (2 << want2) <= nFrames) want2++;
+	for(;;) {
+		long long tier = lp;
+		if(want2 > want) {
+			tier = lp - lp * pct / 100;
+			tier -= tier % 64;                      // tier << logS is a multiple of the block size (256) for logS >= 2
+			if(want < 2) tier -= tier % 256;
+			if(tier < 0) tier = 0;
+		}
+		const long long total = (tier << want) + ((lp - tier) << want2);
+		if(total < (1ll << 31)) {
+			out->logS = want; out->logS2 = want2;
+			out->tierPixels = tier; out->tierThreads = tier << want; out->totalThreads = total;
+			out->blocks = (unsigned)((total + 255) / 256);
+			return PT_OK;
+		}
+		if(want2 > want) want2--;
+		else if(want > 0) { want--; want2 = want; }
+		else return fail(PT_E_INVALID, "pt_render: more than 2^31 - 1 pixels on one rank%s", NULL);
+	}
+}
+
+extern "C" int pt_plan_launch(const pt_render_args *a, pt_launch_plan *out) {
+	if(!a || !out) return fail(PT_E_INVALID, "pt_plan_launch: NULL%s", NULL);
+	if(a->width <= 0 || a->height <= 0 || a->n_frames < 0 || a->first_frame < 0 || (long long)a->width * a->height > (1ll << 30) ||
+	   a->world < 1 || a->rank < 0 || a->rank >= a->world || a->band_rows < 1)
+		return fail(PT_E_INVALID, "pt_plan_launch: bad arguments%s", NULL);
+	const long long lp = local_rows64(a->height, a->rank, a->world, a->band_rows) * a->width;
+	LaunchPlan pl;
+	memset(&pl, 0, sizeof pl);
+	if(lp > 0) { int rc = plan_launch(lp, a->first_frame, a->n_frames, read_switches(), &pl); if(rc != PT_OK) return rc; }
+	out->local_pixels = lp;
+	out->lanes_log2 = pl.logS; out->tail_lanes_log2 = pl.logS2;
+	out->tier_pixels = pl.tierPixels; out->tier_threads = pl.tierThreads; out->total_threads = pl.totalThreads;
+	out->blocks = pl.blocks;
+	return PT_OK;
+}
+
 static int check_render_args(const pt_ctx *c, const pt_render_args *a, const char *who) {
 	if(!c || !a) return fail(PT_E_INVALID, "%s: NULL", who);
 	if(a->width <= 0 || a->height <= 0 || a->max_depth < 0 || a->n_frames < 0 || a->first_frame < 0)
@@ -556,7 +697,7 @@ static int check_render_args(const pt_ctx *c, const pt_render_args *a, const cha
 }
 
 // Kernel choice, launch geometry and the launch itself, shared by pt_render and pt_render_noalloc.  Allocates nothing.
-static int launch_frames(pt_ctx *c, const pt_render_args *a, float4 *img, hipStream_t st, const RenderScratch &rs, bool useGrid) {
+static int launch_frames(pt_ctx *c, const pt_render_args *a, float4 *img, hipStream_t st, const RenderScratch &rs, bool useGrid, const char *who) {
 	KParams p;
 	p.W = a->width; p.H = a->height; p.maxDepth = a->max_depth; p.n = c->nSpheres;
 	p.bgx = a->background[0]; p.bgy = a->background[1]; p.bgz = a->background[2];
@@ -567,66 +708,20 @@ static int launch_frames(pt_ctx *c, const pt_render_args *a, float4 *img, hipStr
 	p.sensorWidth = a->sensor_width; p.focalLength = a->focal_length; p.aperture = a->aperture; p.exposure = a->exposure;
 	p.firstFrame = a->first_frame; p.nFrames = a->n_frames;
 	p.rank = a->rank; p.world = a->world; p.bandRows = a->band_rows;
-	const long long lp = (long long)local_rows(a->height, a->rank, a->world, a->band_rows) * a->width;
+	const long long lp = local_rows64(a->height, a->rank, a->world, a->band_rows) * a->width;
 	p.localPixels = (int)lp;
 	if(lp == 0) return PT_OK;
 
 	SceneTables sc = {c->geom, c->matA, c->matB};
-	// LDS kernel: enough lanes per pixel that the launch has about a dozen rounds of the chip's 8192 wave
-	// slots, at most 16 (measured: the 1080p headline frame 243 ms at 1 lane per pixel, 231 ms at 4; one rank's eighth
-	// of it 32.9 / 28.6 / 26.1 / 25.0 / 24.4 ms at 1 / 2 / 4 / 8 / 16 lanes, 25.1 ms at 32)
-	p.logS = 0;
-	{
-		const char *fs = getenv("PT_LANES_PER_PIXEL");      // debugging aid: force 1, 2, 4 or 8
-		int want = 0;
-		if(fs) { int v = atoi(fs); while((1 << want) < v && want < 6) want++; }
-		else {
-			while(want < 2 && (2 << want) <= a->n_frames) want++;      // 4 lanes whatever the frame size (4K: 734 -> 727 ms)
-			while(want < 4 && (lp << want) < 64ll * 12 * 8192 && (2 << want) <= a->n_frames) want++;
-		}
-		if((long long)a->first_frame + a->n_frames >= (1 << 24)) want = 0;      // the group accumulation counts frames in float
-		p.logS = want;
-		// The tail of the launch: blocks last nFrames / S rounds and the chip drains over about one block time at the
-		// end, so the pixels whose blocks are dispatched last get more lanes each (shorter blocks; bit-identical).
-		// Measured on the headline frame: 4 lanes everywhere 162.3 ms, 8 everywhere 162.4, 4 + the last 8 % at 16: 159.6
-		// (before the running mean was split by channel).
-		int want2 = want;
-		const char *tp = getenv("PT_TAIL_PCT");      // debugging aid: share of the pixels in the second tier, 0 = none
-		const int pct = tp ? atoi(tp) : want >= 4 ? 5 : 3;
-		const bool floatFrames = (long long)a->first_frame + a->n_frames < (1 << 24);      // as for the first tier
-		// A whole wave (64 lanes) per pixel for the last 3 % of a large launch (headline frame: 157.6 ms against 158.2
-		// with 16 lanes for the last 8 %), the last 5 % of a small one whose first tier already has 16 (one rank's
-		// band of eight 20.23 -> 20.1 ms, main.lua's 640x360x2000 144.7 -> 142.8 ms); PT_TAIL_LANES (a debugging
-		// aid) overrides the log2 of the lane limit.
-		const char *tl = getenv("PT_TAIL_LANES");
-		const int cap2 = tl ? atoi(tl) : 6;
-		if((!fs || tp) && pct > 0 && floatFrames) while(want2 < cap2 && want2 < 6 && (2 << want2) <= a->n_frames) want2++;
-		long long tier = lp;
-		if(want2 > want) {
-			tier = lp - lp * pct / 100;
-			tier -= tier % 64;                      // tier << logS is a multiple of the block size (256) for logS >= 2
-			if(want < 2) tier -= tier % 256;
-			if(tier < 0) tier = 0;
-		}
-		p.logS2 = want2;
-		p.tierPixels = (int)tier;
-		p.tierThreads = (int)(tier << want);
-	}
-	// LDS kernel: trios of the table that hold a sphere much smaller than the largest one get a wave-level "can any
-	// lane hit it" test per sphere before the sqrt/select part (closest_hit_lds); a pure speed heuristic, same image.
-	// The mask has 64 bits: trios beyond the first 64 (tables above 192 spheres, reachable only with PT_KERNEL=lds)
-	// always take the unconditional path: correct, only slower.
-	p.trioSkipMask = 0;
-	if(c->hostSpheres && !getenv("PT_NO_TRIO_SKIP")) {
-		float rmax = 0.0f;
-		for(int i = 0; i < c->nSpheres; i++) rmax = fmaxf(rmax, fabsf(c->hostSpheres[i].w));
-		for(int i = 0; i < c->nSpheres && i < 192 && i / 3 < c->nSpheres / 3; i++)
-			if(fabsf(c->hostSpheres[i].w) < rmax * 0.125f) p.trioSkipMask |= 1ull << (i / 3);
-	}
+	LaunchPlan plan;
+	if(plan_launch(lp, a->first_frame, a->n_frames, c->sw, &plan) != PT_OK) return PT_E_INVALID;
+	p.logS = plan.logS; p.logS2 = plan.logS2;
+	p.tierPixels = (int)plan.tierPixels; p.tierThreads = (int)plan.tierThreads;
+	p.trioSkipMask = c->sw.noTrioSkip ? 0ull : c->sceneTrioMask;      // derived from the scene at pt_scene_upload
 	LaunchArgs la;
 	la.image = img; la.p = p; la.sc = sc; la.seedmul = rs.seedmul; la.bounceCounter = rs.counter; la.queue = rs.queue;
 	la.stream = st; la.count = a->bounce_count != NULL;
-	la.gridPixels = (unsigned)((((long long)p.tierThreads + ((lp - p.tierPixels) << p.logS2)) + 255) / 256);
+	la.gridPixels = plan.blocks;
 	// Up to PT_LOCKSTEP_MAX_SPHERES spheres: the lock-step kernel with the whole table in LDS and a branch-free
 	// scan (the reference's own scene has 9).  Beyond that the persistent streaming kernel wins on open scenes even
 	// where the table would still fit in LDS, because paths end after a few bounces and its lanes never idle (1080p,
@@ -635,23 +730,28 @@ static int launch_frames(pt_ctx *c, const pt_render_args *a, float4 *img, hipStr
 	// depth 32: 39 spheres 31.7 vs 45.9 ms; 72: 54.7 vs 69.3; 133: 92.5 vs 106.4; 224: 158 vs 149; 351: 274 vs 232):
 	// it is chosen up to PT_LOCKSTEP_MAX_CLOSED when rays from the camera in all 26 axis and diagonal directions hit
 	// something.  Either kernel gives the same image.
-	const char *force = getenv("PT_KERNEL");      // debugging aid: "stream" or "lds" overrides the choice
 	la.kernel = c->nSpheres <= PT_LOCKSTEP_MAX_SPHERES ? PT_K_LDS : PT_K_STREAM;
-	if(la.kernel == PT_K_STREAM && c->nSpheres <= PT_LOCKSTEP_MAX_CLOSED && camera_is_enclosed(c, a->cam_pos)) la.kernel = PT_K_LDS;
-	if(force && strcmp(force, "stream") == 0 && c->nSpheres > 0) la.kernel = PT_K_STREAM;
-	if(force && strcmp(force, "lds") == 0 && c->nSpheres <= PT_LDS_MAX_SPHERES) la.kernel = PT_K_LDS;
+	if(la.kernel == PT_K_STREAM && c->nSpheres <= PT_LOCKSTEP_MAX_CLOSED && c->sw.kernel == 0) {
+		// asked once per camera position (the 26 probes walk the whole host table)
+		if(!c->enclosedKnown || memcmp(c->enclosedPos, a->cam_pos, sizeof c->enclosedPos) != 0) {
+			c->enclosed = camera_is_enclosed(c, a->cam_pos) ? 1 : 0;
+			memcpy(c->enclosedPos, a->cam_pos, sizeof c->enclosedPos);
+			c->enclosedKnown = 1;
+		}
+		if(c->enclosed) la.kernel = PT_K_LDS;
+	}
+	// PT_KERNEL (debugging aid): "stream" or "lds" overrides the choice
+	if(c->sw.kernel == 1 && c->nSpheres > 0) la.kernel = PT_K_STREAM;
+	if(c->sw.kernel == 2 && c->nSpheres <= PT_LDS_MAX_SPHERES) la.kernel = PT_K_LDS;
 	memset(&la.grid, 0, sizeof la.grid);
 	if(useGrid) { la.grid = c->grid; la.kernel = PT_K_GRID; }
 	la.ldsBytes = la.kernel == PT_K_LDS ? pt_strict::lds_table_bytes(c->nSpheres) : 0;
-	la.genericScan = getenv("PT_GENERIC_SCAN") != NULL;
+	la.genericScan = c->sw.genericScan;
 	// streaming kernel: persistent one-wave blocks, at most 32 per CU; surplus pixels come through the queue
 	const long long swaves = (lp + 63) / 64;
 	la.gridStream = (unsigned)(swaves < 256 * 32 ? swaves : 256 * 32);
 	// float rules: strict (bit-identical to the oracle) unless the caller, or PT_MATH=fast, asks for the relaxed build
-	bool fast = a->fast_math != 0;
-	const char *math = getenv("PT_MATH");
-	if(math && strcmp(math, "fast") == 0) fast = true;
-	if(math && strcmp(math, "strict") == 0) fast = false;
+	const bool fast = c->sw.math == 1 || (c->sw.math == 0 && a->fast_math != 0);
 
 	if(la.kernel == PT_K_STREAM || la.kernel == PT_K_GRID) HIP_TRY(hipMemsetAsync(rs.queue, 0, 256, st));     // before the start event: not kernel time
 	if(a->bounce_count) {
@@ -666,7 +766,7 @@ static int launch_frames(pt_ctx *c, const pt_render_args *a, float4 *img, hipStr
 	}
 	const bool ringTimed = a->record_timing && !a->kernel_ms;
 	if(ringTimed && c->nTimed >= PT_TIMING_SLOTS)
-		return fail(PT_E_STATE, "pt_render: timing ring full (call pt_kernel_times)%s", NULL);
+		return fail(PT_E_STATE, "%s: timing ring full (call pt_kernel_times)", who);
 	if(a->kernel_ms) HIP_TRY(hipEventRecord(c->evStart, st));
 	if(ringTimed) HIP_TRY(hipEventRecord(c->ring[2 * c->nTimed], st));
 	if(fast) pt_fast::launch_render(la); else pt_strict::launch_render(la);
@@ -714,14 +814,10 @@ extern "C" int pt_render(pt_ctx *c, const pt_render_args *a) {
 	}
 
 	// opt-in acceleration structure (no reference counterpart): same closest hit, found through a uniform grid
-	bool accel = a->accel == 1;
-	const char *acc = getenv("PT_ACCEL");
-	if(acc && strcmp(acc, "grid") == 0) accel = true;
-	if(acc && strcmp(acc, "none") == 0) accel = false;
-	accel = accel && c->nSpheres > 0;
+	const bool accel = (c->sw.accel == 1 || (c->sw.accel == 0 && a->accel == 1)) && c->nSpheres > 0;
 	if(accel && !c->gridBuilt) { rc = build_grid(c, st); if(rc != PT_OK) return rc; }
 	const RenderScratch rs = {c->seedmul, c->counter, c->queue};
-	return launch_frames(c, a, img, st, rs, accel);
+	return launch_frames(c, a, img, st, rs, accel, "pt_render");
 }
 
 // pt_render for callers that cannot allocate (include/pt_hip.h).  Same kernels, same image; the working memory is
@@ -738,6 +834,24 @@ extern "C" int pt_render_noalloc(pt_ctx *c, const pt_render_args *a) {
 	HIP_TRY(hipSetDevice(c->device));
 	hipStream_t st = a->stream ? (hipStream_t)a->stream : c->stream;
 	if(a->n_frames == 0) return PT_OK;
+	// Under stream capture nothing may synchronise: only the enqueue-and-return form is legal there.
+	hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+	HIP_TRY(hipStreamIsCapturing(st, &cap));
+	const bool capturing = cap != hipStreamCaptureStatusNone;
+	if(capturing && (!a->async || a->bounce_count || a->kernel_ms || a->record_timing))
+		return fail(PT_E_INVALID, "pt_render_noalloc: the stream is being captured — async must be 1 and bounce_count, kernel_ms, record_timing unset (they synchronise or record timing events)%s", NULL);
+	// One call at a time per GPU on the shared scratch: same stream = ordered; another stream must have finished.
+	std::unique_lock<std::mutex> inflight(g_noallocLock, std::defer_lock);
+	NoallocSlot *slot = c->device < PT_MAX_DEVICES ? &g_noalloc[c->device] : NULL;
+	if(slot && !capturing) {
+		inflight.lock();
+		if(slot->armed && slot->stream != st) {
+			const hipError_t q = hipEventQuery(slot->ev);
+			if(q == hipErrorNotReady)
+				return fail(PT_E_STATE, "pt_render_noalloc: an earlier call on this GPU is still running on another stream; the calls share one scratch array (include/pt_hip.h)%s", NULL);
+			if(q != hipSuccess) { (void)hipGetLastError(); slot->armed = false; }
+		}
+	}
 	unsigned char *const sp = c->scratchPtr;      // the device address, never the array's name
 	uint64_t *const dSeeds = (uint64_t *)(sp + PT_SCRATCH_SEEDS_OFF);
 	for(int k0 = 0; k0 < a->n_frames; k0 += 256) {
@@ -749,18 +863,59 @@ extern "C" int pt_render_noalloc(pt_ctx *c, const pt_render_args *a) {
 		HIP_TRY(hipGetLastError());
 	}
 	const RenderScratch rs = {dSeeds, (unsigned long long *)(sp + PT_SCRATCH_COUNTER_OFF), (unsigned int *)(sp + PT_SCRATCH_QUEUE_OFF)};
-	return launch_frames(c, a, img, st, rs, false);
+	rc = launch_frames(c, a, img, st, rs, false, "pt_render_noalloc");
+	if(slot && !capturing) {
+		if(hipEventRecord(slot->ev, st) == hipSuccess) { slot->stream = st; slot->armed = true; }
+		else { (void)hipGetLastError(); slot->armed = false; }
+	}
+	return rc;
 }
 
 // ---------------------------------------------------------------------------------------
-// Multi-GPU combine (include/pt_hip.h pt_combine_bands): the root's accumulator receives every other rank's
-// row bands — in place, each band exactly once — as ONE group of RCCL point-to-point transfers over xGMI.
-// librccl is loaded on first use (dlopen), so a single-GPU user never maps it.
+// Multi-GPU combine (include/pt_hip.h pt_combine_bands, pt_combine_bands_rank): the root's accumulator receives
+// every other rank's row bands, each band exactly once, as ONE message per peer: a rank's bands are packed into a
+// compact staging buffer in the order the render kernel itself numbers its pixels (pixel_id(): local pixel t ->
+// global work-item id), travel as one RCCL send/recv pair over the peer's own xGMI link, and are unpacked into the
+// root's accumulator through the same map.  Bytes moved = the image minus the root's own bands, in world - 1
+// messages.  librccl is loaded on first use (dlopen), so a single-GPU user never maps it; where it cannot be set
+// up, one process driving several GPUs falls back to peer copies of the same packed buffers.
 // ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pt_bands_kernel(float4 *__restrict__ image, float4 *__restrict__ stage, const KParams p, const int unpack) {
+	const int t = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+	const int id = pixel_id(p, t);      // -1 past this rank's pixels
+	if(id < 0) return;
+	if(unpack) image[id] = stage[t];
+	else stage[t] = image[id];
+}
+
+// pack (image -> stage) or unpack (stage -> image) the bands of `rank` on stream st; returns the pixel count
+static int bands_copy(float4 *image, float4 *stage, int W, int H, int rank, int world, int band, int unpack, hipStream_t st) {
+	KParams p;
+	memset(&p, 0, sizeof p);
+	p.W = W; p.H = H; p.rank = rank; p.world = world; p.bandRows = band;
+	const long long lp = local_rows64(H, rank, world, band) * W;
+	p.localPixels = (int)lp;
+	if(lp == 0) return PT_OK;
+	hipLaunchKernelGGL(pt_bands_kernel, dim3((unsigned)((lp + 255) / 256)), dim3(256), 0, st, image, stage, p, unpack);
+	HIP_TRY(hipGetLastError());
+	return PT_OK;
+}
+
+static int grow_stage(pt_ctx *c, size_t pixels) {
+	if(pixels <= c->capStage) return PT_OK;
+	if(c->stage) { HIP_TRY(hipFree(c->stage)); c->stage = NULL; c->capStage = 0; }
+	HIP_TRY(hipMalloc((void **)&c->stage, sizeof(float4) * pixels));
+	c->capStage = pixels;
+	return PT_OK;
+}
+
 namespace {
 struct RcclApi {
 	void *lib;
 	decltype(&ncclCommInitAll) commInitAll;
+	decltype(&ncclCommInitRank) commInitRank;
+	decltype(&ncclGetUniqueId) getUniqueId;
+	decltype(&ncclCommDestroy) commDestroy;
 	decltype(&ncclGroupStart) groupStart;
 	decltype(&ncclGroupEnd) groupEnd;
 	decltype(&ncclSend) send;
@@ -771,27 +926,47 @@ RcclApi g_rccl;
 std::mutex g_rcclLock;
 struct CommSet { int n; int dev[8]; ncclComm_t comm[8]; };
 std::vector<CommSet> g_comms;      // one set per distinct device list, kept for the life of the process
+thread_local const char *g_transport = "";
 
 int rccl_load() {
 	if(g_rccl.lib) return PT_OK;
 	const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
 	void *lib = NULL;
 	for(const char *nm : names) if((lib = dlopen(nm, RTLD_NOW | RTLD_LOCAL))) break;
-	if(!lib) return fail(PT_E_DEVICE, "pt_combine_bands: cannot load librccl: %s", dlerror());
+	if(!lib) return fail(PT_E_DEVICE, "cannot load librccl: %s", dlerror());
 	RcclApi a;
 	a.lib = lib;
 	a.commInitAll = (decltype(a.commInitAll))dlsym(lib, "ncclCommInitAll");
+	a.commInitRank = (decltype(a.commInitRank))dlsym(lib, "ncclCommInitRank");
+	a.getUniqueId = (decltype(a.getUniqueId))dlsym(lib, "ncclGetUniqueId");
+	a.commDestroy = (decltype(a.commDestroy))dlsym(lib, "ncclCommDestroy");
 	a.groupStart = (decltype(a.groupStart))dlsym(lib, "ncclGroupStart");
 	a.groupEnd = (decltype(a.groupEnd))dlsym(lib, "ncclGroupEnd");
 	a.send = (decltype(a.send))dlsym(lib, "ncclSend");
 	a.recv = (decltype(a.recv))dlsym(lib, "ncclRecv");
 	a.errorString = (decltype(a.errorString))dlsym(lib, "ncclGetErrorString");
-	if(!a.commInitAll || !a.groupStart || !a.groupEnd || !a.send || !a.recv || !a.errorString) {
+	if(!a.commInitAll || !a.commInitRank || !a.getUniqueId || !a.commDestroy || !a.groupStart || !a.groupEnd || !a.send || !a.recv || !a.errorString) {
 		dlclose(lib);
-		return fail(PT_E_DEVICE, "pt_combine_bands: librccl lacks a symbol%s", NULL);
+		return fail(PT_E_DEVICE, "librccl lacks a symbol%s", NULL);
 	}
 	g_rccl = a;
 	return PT_OK;
+}
+
+// the communicators of one process driving the GPUs of ctxs[0..n): created once per device list
+CommSet *comm_set(pt_ctx *const *ctxs, int n) {
+	for(auto &c : g_comms) {
+		bool same = c.n == n;
+		for(int i = 0; same && i < n; i++) same = c.dev[i] == ctxs[i]->device;
+		if(same) return &c;
+	}
+	CommSet c;
+	c.n = n;
+	for(int i = 0; i < n; i++) c.dev[i] = ctxs[i]->device;
+	const ncclResult_t r = g_rccl.commInitAll(c.comm, n, c.dev);
+	if(r != ncclSuccess) { snprintf(g_err, sizeof g_err, "ncclCommInitAll failed: %s", g_rccl.errorString(r)); return NULL; }
+	g_comms.push_back(c);
+	return &g_comms.back();
 }
 }   // namespace
 
@@ -804,79 +979,171 @@ int rccl_load() {
 		}                                                                                            \
 	} while(0)
 
+extern "C" const char *pt_combine_transport(void) { return g_transport; }
+
+static void pt_comm_release(pt_ctx *c) {
+	if(c->mpComm && g_rccl.lib) (void)g_rccl.commDestroy((ncclComm_t)c->mpComm);
+	c->mpComm = NULL;
+}
+
 extern "C" int pt_combine_bands(pt_ctx *const *ctxs, int n, int root, int band_rows) {
 	if(!ctxs || n < 1 || n > 8 || root < 0 || root >= n || band_rows < 1) return fail(PT_E_INVALID, "pt_combine_bands: bad arguments%s", NULL);
 	for(int i = 0; i < n; i++) {
 		if(!ctxs[i] || !ctxs[i]->image) return fail(PT_E_STATE, "pt_combine_bands: a context has no accumulator (pt_image_alloc)%s", NULL);
 		if(ctxs[i]->imgW != ctxs[root]->imgW || ctxs[i]->imgH != ctxs[root]->imgH) return fail(PT_E_STATE, "pt_combine_bands: accumulators differ in size%s", NULL);
 	}
+	g_transport = "none";
 	if(n == 1) return PT_OK;
 	pt_ctx *const R = ctxs[root];
 	const int W = R->imgW, H = R->imgH;
-	const int nb = (H + band_rows - 1) / band_rows;
-	// ranks that share the root's GPU (PT_SHARE_GPU debugging set-ups: several contexts on one device) cannot be RCCL
-	// peers of it; their bands are device-to-device copies on the root's stream, ordered after the rank's own stream
 	bool anyRemote = false, distinct = true;
 	for(int i = 0; i < n; i++) {
 		if(ctxs[i]->device != R->device) anyRemote = true;
 		for(int j = 0; j < i; j++) if(ctxs[i]->device == ctxs[j]->device) distinct = false;
 	}
 	if(anyRemote && !distinct) return fail(PT_E_INVALID, "pt_combine_bands: ranks must be on distinct GPUs, or all on one%s", NULL);
-	if(!anyRemote) {
-		HIP_TRY(hipSetDevice(R->device));
-		for(int i = 0; i < n; i++) {
-			if(i == root) continue;
-			HIP_TRY(hipEventRecord(ctxs[i]->evStop, ctxs[i]->stream));
-			HIP_TRY(hipStreamWaitEvent(R->stream, ctxs[i]->evStop, 0));
-		}
-		for(int b = 0; b < nb; b++) {
-			const int r = b % n;
-			if(r == root) continue;
-			const int row0 = b * band_rows, rows = row0 + band_rows <= H ? band_rows : H - row0;
-			const size_t off = (size_t)row0 * W, cnt = (size_t)rows * W;
-			HIP_TRY(hipMemcpyAsync(R->image + off, ctxs[r]->image + off, cnt * sizeof(float4), hipMemcpyDeviceToDevice, R->stream));
-		}
-		return PT_OK;
+	// 1. every peer packs its bands on its own stream (ordered after its render); the root makes room for all of them
+	size_t cnt[8], off[8], total = 0;
+	for(int r = 0; r < n; r++) {
+		cnt[r] = (size_t)(local_rows64(H, r, n, band_rows) * W);
+		off[r] = total;
+		if(r != root) total += cnt[r];
 	}
+	int rc;
+	for(int r = 0; r < n; r++) {
+		if(r == root || cnt[r] == 0) continue;
+		HIP_TRY(hipSetDevice(ctxs[r]->device));
+		if((rc = grow_stage(ctxs[r], cnt[r])) != PT_OK) return rc;
+		if((rc = bands_copy(ctxs[r]->image, ctxs[r]->stage, W, H, r, n, band_rows, 0, ctxs[r]->stream)) != PT_OK) return rc;
+	}
+	HIP_TRY(hipSetDevice(R->device));
+	if((rc = grow_stage(R, total)) != PT_OK) return rc;
+	// 2. one message per peer.  Distinct GPUs: RCCL send/recv pairs in one group (each peer over its own xGMI link); if
+	// RCCL cannot be set up (library, symbols, communicators) peer copies of the same buffers, ordered by events, take
+	// its place (PT_COMBINE=copy asks for them, PT_COMBINE=rccl forbids the fallback).  One GPU (PT_SHARE_GPU debugging
+	// set-ups, several contexts on one device, which cannot be RCCL peers): device copies.
+	bool useRccl = anyRemote && R->sw.combine != 1;
+	if(useRccl) {
+		std::lock_guard<std::mutex> lock(g_rcclLock);
+		CommSet *cs = rccl_load() == PT_OK ? comm_set(ctxs, n) : NULL;
+		if(!cs) {
+			if(R->sw.combine == 2) return PT_E_DEVICE;      // g_err holds the reason
+			fprintf(stderr, "pt_combine_bands: RCCL unavailable (%s); using peer copies\n", g_err);
+			useRccl = false;
+		} else {
+			RCCL_TRY(g_rccl.groupStart());
+			for(int r = 0; r < n; r++) {
+				if(r == root || cnt[r] == 0) continue;
+				// each call with its communicator's device current (one process drives all ranks)
+				hipError_t d1 = hipSetDevice(ctxs[r]->device);
+				ncclResult_t e1 = g_rccl.send(ctxs[r]->stage, cnt[r] * 4, ncclFloat, root, cs->comm[r], ctxs[r]->stream);
+				hipError_t d2 = hipSetDevice(R->device);
+				ncclResult_t e2 = g_rccl.recv(R->stage + off[r], cnt[r] * 4, ncclFloat, r, cs->comm[root], R->stream);
+				if(d1 != hipSuccess || d2 != hipSuccess) { (void)g_rccl.groupEnd(); return fail(PT_E_DEVICE, "pt_combine_bands: hipSetDevice failed%s", NULL); }
+				if(e1 != ncclSuccess || e2 != ncclSuccess) {
+					(void)g_rccl.groupEnd();
+					snprintf(g_err, sizeof g_err, "pt_combine_bands: ncclSend/ncclRecv failed: %s", g_rccl.errorString(e1 != ncclSuccess ? e1 : e2));
+					return PT_E_DEVICE;
+				}
+			}
+			RCCL_TRY(g_rccl.groupEnd());
+			g_transport = "rccl";
+		}
+	}
+	if(!useRccl) {
+		for(int r = 0; r < n; r++) {
+			if(r == root || cnt[r] == 0) continue;
+			HIP_TRY(hipSetDevice(ctxs[r]->device));
+			HIP_TRY(hipEventRecord(ctxs[r]->evStop, ctxs[r]->stream));
+			HIP_TRY(hipSetDevice(R->device));
+			HIP_TRY(hipStreamWaitEvent(R->stream, ctxs[r]->evStop, 0));
+			if(ctxs[r]->device == R->device)
+				HIP_TRY(hipMemcpyAsync(R->stage + off[r], ctxs[r]->stage, cnt[r] * sizeof(float4), hipMemcpyDeviceToDevice, R->stream));
+			else
+				HIP_TRY(hipMemcpyPeerAsync(R->stage + off[r], R->device, ctxs[r]->stage, ctxs[r]->device, cnt[r] * sizeof(float4), R->stream));
+		}
+		g_transport = anyRemote ? "peer-copy" : "device-copy";
+	}
+	// 3. the root scatters every peer's bands into its accumulator (its stream: after the receives)
+	HIP_TRY(hipSetDevice(R->device));
+	for(int r = 0; r < n; r++) {
+		if(r == root || cnt[r] == 0) continue;
+		if((rc = bands_copy(R->image, R->stage + off[r], W, H, r, n, band_rows, 1, R->stream)) != PT_OK) return rc;
+	}
+	return PT_OK;
+}
+
+// ---- the same combine for one process PER GPU (bench.py --gpus N under torch.distributed.run) -------------------
+extern "C" int pt_comm_unique_id(void *id, int bytes) {
+	if(!id || bytes < (int)sizeof(ncclUniqueId)) return fail(PT_E_INVALID, "pt_comm_unique_id: need a buffer of PT_COMM_ID_BYTES%s", NULL);
 	std::lock_guard<std::mutex> lock(g_rcclLock);
 	int rc = rccl_load();
 	if(rc != PT_OK) return rc;
-	CommSet *cs = NULL;
-	for(auto &c : g_comms) {
-		bool same = c.n == n;
-		for(int i = 0; same && i < n; i++) same = c.dev[i] == ctxs[i]->device;
-		if(same) { cs = &c; break; }
+	ncclUniqueId u;
+	RCCL_TRY(g_rccl.getUniqueId(&u));
+	memset(id, 0, (size_t)bytes);
+	memcpy(id, &u, sizeof u);
+	return PT_OK;
+}
+
+extern "C" int pt_comm_init_rank(pt_ctx *c, int world, int rank, const void *id) {
+	if(!c || !id || world < 1 || rank < 0 || rank >= world) return fail(PT_E_INVALID, "pt_comm_init_rank: bad arguments%s", NULL);
+	std::lock_guard<std::mutex> lock(g_rcclLock);
+	int rc = rccl_load();
+	if(rc != PT_OK) return rc;
+	HIP_TRY(hipSetDevice(c->device));
+	if(c->mpComm) { (void)g_rccl.commDestroy((ncclComm_t)c->mpComm); c->mpComm = NULL; }
+	ncclUniqueId u;
+	memcpy(&u, id, sizeof u);
+	ncclComm_t comm;
+	RCCL_TRY(g_rccl.commInitRank(&comm, world, u, rank));
+	c->mpComm = comm; c->mpWorld = world; c->mpRank = rank;
+	return PT_OK;
+}
+
+extern "C" int pt_combine_bands_rank(pt_ctx *c, int root, int band_rows, void *d_image, int width, int height, void *stream) {
+	if(!c || band_rows < 1) return fail(PT_E_INVALID, "pt_combine_bands_rank: bad arguments%s", NULL);
+	if(!c->mpComm) return fail(PT_E_STATE, "pt_combine_bands_rank: no communicator (pt_comm_init_rank)%s", NULL);
+	const int n = c->mpWorld, me = c->mpRank;
+	if(root < 0 || root >= n) return fail(PT_E_INVALID, "pt_combine_bands_rank: bad root%s", NULL);
+	float4 *img = (float4 *)d_image;
+	if(!img) {
+		if(!c->image) return fail(PT_E_STATE, "pt_combine_bands_rank: no accumulator (call pt_image_alloc)%s", NULL);
+		img = c->image; width = c->imgW; height = c->imgH;
 	}
-	if(!cs) {
-		CommSet c;
-		c.n = n;
-		for(int i = 0; i < n; i++) c.dev[i] = ctxs[i]->device;
-		RCCL_TRY(g_rccl.commInitAll(c.comm, n, c.dev));      // one process drives all ranks
-		g_comms.push_back(c);
-		cs = &g_comms.back();
+	if(width <= 0 || height <= 0 || (long long)width * height > (1ll << 30)) return fail(PT_E_INVALID, "pt_combine_bands_rank: bad size%s", NULL);
+	HIP_TRY(hipSetDevice(c->device));
+	hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+	g_transport = n == 1 ? "none" : "rccl";
+	if(n == 1) return PT_OK;
+	int rc;
+	if(me != root) {
+		const size_t cnt = (size_t)(local_rows64(height, me, n, band_rows) * width);
+		if(cnt == 0) return PT_OK;
+		if((rc = grow_stage(c, cnt)) != PT_OK) return rc;
+		if((rc = bands_copy(img, c->stage, width, height, me, n, band_rows, 0, st)) != PT_OK) return rc;
+		RCCL_TRY(g_rccl.send(c->stage, cnt * 4, ncclFloat, root, (ncclComm_t)c->mpComm, st));
+		return PT_OK;
 	}
-	// every band not owned by the root: ncclSend on the owner's stream (ordered after its render), ncclRecv on the root's
-	// stream straight into the root's accumulator at the band's offset.  One group: the transfers run concurrently, each
-	// peer over its own xGMI link.  Bytes moved = the image minus the root's own bands, once.
+	size_t cnt[64], off[64], total = 0;
+	if(n > 64) return fail(PT_E_INVALID, "pt_combine_bands_rank: more than 64 ranks%s", NULL);
+	for(int r = 0; r < n; r++) {
+		cnt[r] = (size_t)(local_rows64(height, r, n, band_rows) * width);
+		off[r] = total;
+		if(r != root) total += cnt[r];
+	}
+	if((rc = grow_stage(c, total)) != PT_OK) return rc;
 	RCCL_TRY(g_rccl.groupStart());
-	for(int b = 0; b < nb; b++) {
-		const int r = b % n;
-		if(r == root) continue;
-		const int row0 = b * band_rows, rows = row0 + band_rows <= H ? band_rows : H - row0;
-		const size_t off = (size_t)row0 * W, cnt = (size_t)rows * W * 4;
-		// each call with its communicator's device current (one process drives all ranks)
-		hipError_t d1 = hipSetDevice(ctxs[r]->device);
-		ncclResult_t e1 = g_rccl.send(ctxs[r]->image + off, cnt, ncclFloat, root, cs->comm[r], ctxs[r]->stream);
-		hipError_t d2 = hipSetDevice(R->device);
-		ncclResult_t e2 = g_rccl.recv(R->image + off, cnt, ncclFloat, r, cs->comm[root], R->stream);
-		if(d1 != hipSuccess || d2 != hipSuccess) { (void)g_rccl.groupEnd(); return fail(PT_E_DEVICE, "pt_combine_bands: hipSetDevice failed%s", NULL); }
-		if(e1 != ncclSuccess || e2 != ncclSuccess) {
-			(void)g_rccl.groupEnd();
-			snprintf(g_err, sizeof g_err, "pt_combine_bands: ncclSend/ncclRecv failed: %s", g_rccl.errorString(e1 != ncclSuccess ? e1 : e2));
-			return PT_E_DEVICE;
-		}
+	for(int r = 0; r < n; r++) {
+		if(r == root || cnt[r] == 0) continue;
+		const ncclResult_t e = g_rccl.recv(c->stage + off[r], cnt[r] * 4, ncclFloat, r, (ncclComm_t)c->mpComm, st);
+		if(e != ncclSuccess) { (void)g_rccl.groupEnd(); snprintf(g_err, sizeof g_err, "pt_combine_bands_rank: ncclRecv failed: %s", g_rccl.errorString(e)); return PT_E_DEVICE; }
 	}
 	RCCL_TRY(g_rccl.groupEnd());
+	for(int r = 0; r < n; r++) {
+		if(r == root || cnt[r] == 0) continue;
+		if((rc = bands_copy(img, c->stage + off[r], width, height, r, n, band_rows, 1, st)) != PT_OK) return rc;
+	}
 	return PT_OK;
 }
 

@@ -356,9 +356,14 @@ Image *render(Renderer *renderer, int samples, int verbose) {
 	image->width = W; image->height = H;
 	image->data = malloc(3 * (size_t)W * (size_t)H);
 	if(!image->data) { free(image); return NULL; }
-	/* several GPUs: the other ranks' bands travel into rank 0's accumulator over xGMI (one group of RCCL transfers,
-	 * pt_combine_bands), then ONE conversion and ONE 3-byte-per-pixel read-back, as with a single GPU */
-	if(b->n > 1 && samples > 0 && pt_combine_bands(b->ctx, b->n, 0, PT_BAND_ROWS) != PT_OK) { destroy_image(image); return render_failed(renderer, "combine"); }
+	/* several GPUs: the other ranks' bands travel into rank 0's accumulator over xGMI (one packed RCCL message per rank,
+	 * peer copies where RCCL cannot be set up: pt_combine_bands), then ONE conversion and ONE 3-byte-per-pixel
+	 * read-back, as with a single GPU */
+	if(b->n > 1 && samples > 0) {
+		if(pt_combine_bands(b->ctx, b->n, 0, PT_BAND_ROWS) != PT_OK) { destroy_image(image); return render_failed(renderer, "combine"); }
+		static int told;
+		if(!told) { told = 1; host_msg("multi-GPU combine over %d ranks: %s\n", b->n, pt_combine_transport()); }
+	}
 	if(pt_image_read_u8(b->ctx[0], NULL, 0, 0, image->data) != PT_OK) { destroy_image(image); return render_failed(renderer, "read-back"); }
 	return image;
 }

@@ -42,8 +42,24 @@ class RenderArgs(C.Structure):
 _lib = None
 
 # every symbol include/pt_hip.h declares
-EXPORTS = ["pt_last_error", "pt_device_count", "pt_ctx_create", "pt_ctx_destroy", "pt_image_alloc",
-           "pt_scene_upload", "pt_render", "pt_render_noalloc", "pt_combine_bands", "pt_kernel_times", "pt_sync", "pt_image_read", "pt_image_read_u8", "pt_selftest"]
+EXPORTS = ["pt_last_error", "pt_device_count", "pt_ctx_create", "pt_ctx_destroy", "pt_ctx_reload_env", "pt_image_alloc",
+           "pt_scene_upload", "pt_plan_launch", "pt_render", "pt_render_noalloc", "pt_combine_bands", "pt_combine_transport",
+           "pt_comm_unique_id", "pt_comm_init_rank", "pt_combine_bands_rank",
+           "pt_kernel_times", "pt_sync", "pt_image_read", "pt_image_read_u8", "pt_selftest"]
+COMM_ID_BYTES = 128
+# the PT_* switches a context reads once at creation (include/pt_hip.h pt_ctx_reload_env)
+ENV_SWITCHES = ("PT_MATH", "PT_ACCEL", "PT_KERNEL", "PT_GENERIC_SCAN", "PT_NO_TRIO_SKIP", "PT_LANES_PER_PIXEL",
+                "PT_TAIL_PCT", "PT_TAIL_LANES", "PT_COMBINE")
+
+
+class LaunchPlan(C.Structure):
+    _fields_ = [("local_pixels", C.c_longlong), ("lanes_log2", C.c_int), ("tail_lanes_log2", C.c_int),
+                ("tier_pixels", C.c_longlong), ("tier_threads", C.c_longlong), ("total_threads", C.c_longlong),
+                ("blocks", C.c_uint)]
+
+
+def _env_state():
+    return tuple(os.environ.get(k) for k in ENV_SWITCHES)
 
 
 def load():
@@ -55,6 +71,12 @@ def load():
         raise PtError("%s not found — build it with `python -c 'import __graft_entry__ as g; g.build()'`" % LIB_PATH)
     lib = C.CDLL(LIB_PATH)
     lib.pt_last_error.restype = C.c_char_p
+    lib.pt_combine_transport.restype = C.c_char_p
+    lib.pt_ctx_reload_env.argtypes = [C.c_void_p]
+    lib.pt_plan_launch.argtypes = [C.POINTER(RenderArgs), C.POINTER(LaunchPlan)]
+    lib.pt_comm_unique_id.argtypes = [C.c_void_p, C.c_int]
+    lib.pt_comm_init_rank.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    lib.pt_combine_bands_rank.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     lib.pt_device_count.argtypes = [C.POINTER(C.c_int)]
     lib.pt_ctx_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
     lib.pt_ctx_destroy.argtypes = [C.c_void_p]
@@ -70,7 +92,7 @@ def load():
     lib.pt_selftest.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
                                 C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_float)]
     for name in EXPORTS:
-        if name != "pt_last_error":
+        if name not in ("pt_last_error", "pt_combine_transport"):
             getattr(lib, name).restype = C.c_int
     _lib = lib
     return lib
@@ -96,6 +118,7 @@ class Context:
         _check(self.lib.pt_ctx_create(device, C.byref(h)), "pt_ctx_create")
         self.h = h
         self.size = None
+        self._env = _env_state()
 
     def close(self):
         if self.h:
@@ -123,6 +146,9 @@ class Context:
         been uploaded with scene_upload().  Returns the bounce count (count_bounces) or the
         HIP-event kernel time in ms (time_kernel) if asked, else None."""
         seeds = np.ascontiguousarray(seeds, np.uint64)
+        if _env_state() != self._env:      # the tests flip PT_* switches between renders; the library reads them once per context
+            self._env = _env_state()
+            _check(self.lib.pt_ctx_reload_env(self.h), "pt_ctx_reload_env")
         a = RenderArgs()
         a.width, a.height, a.max_depth = width, height, max_depth
         bg = np.asarray(scene["bg"], np.float32)
@@ -162,6 +188,14 @@ class Context:
     def sync(self):
         _check(self.lib.pt_sync(self.h), "pt_sync")
 
+    def comm_init_rank(self, world, rank, comm_id):
+        buf = C.create_string_buffer(bytes(comm_id), COMM_ID_BYTES)
+        _check(self.lib.pt_comm_init_rank(self.h, world, rank, buf), "pt_comm_init_rank")
+
+    def combine_bands_rank(self, root, band_rows, d_image=None, width=0, height=0, stream=None):
+        _check(self.lib.pt_combine_bands_rank(self.h, root, band_rows, d_image, width, height, stream), "pt_combine_bands_rank")
+        return self.lib.pt_combine_transport().decode()
+
     def image_read(self):
         w, h = self.size
         out = np.empty((h, w, 4), np.float32)
@@ -192,9 +226,30 @@ class Context:
 
 
 def combine_bands(ctxs, root, band_rows):
-    """pt_combine_bands over a list of Context objects (rank i = ctxs[i])."""
+    """pt_combine_bands over a list of Context objects (rank i = ctxs[i]); returns the transport that was used."""
+    for c in ctxs:
+        if _env_state() != c._env:
+            c._env = _env_state()
+            _check(c.lib.pt_ctx_reload_env(c.h), "pt_ctx_reload_env")
     arr = (C.c_void_p * len(ctxs))(*[c.h for c in ctxs])
     _check(load().pt_combine_bands(arr, len(ctxs), root, band_rows), "pt_combine_bands")
+    return load().pt_combine_transport().decode()
+
+
+def plan_launch(width, height, n_frames, first_frame=0, rank=0, world=1, band_rows=8):
+    """pt_plan_launch: the lock-step kernel's launch geometry for these arguments (host arithmetic, no GPU)."""
+    a = RenderArgs()
+    a.width, a.height, a.n_frames, a.first_frame = width, height, n_frames, first_frame
+    a.rank, a.world, a.band_rows = rank, world, band_rows
+    out = LaunchPlan()
+    _check(load().pt_plan_launch(C.byref(a), C.byref(out)), "pt_plan_launch")
+    return out
+
+
+def comm_unique_id():
+    buf = C.create_string_buffer(COMM_ID_BYTES)
+    _check(load().pt_comm_unique_id(buf, COMM_ID_BYTES), "pt_comm_unique_id")
+    return buf.raw
 
 
 def render_scene(ctx, scene, width, height, max_depth, seeds, **kw):

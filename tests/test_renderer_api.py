@@ -152,9 +152,14 @@ def test_combine_bands_through_the_c_abi(ctx, oracle):
             c.scene_upload(sc["spheres"])
             c.image_alloc(W, H)
             c.render(sc, W, H, 32, s, rank=r, world=3, band_rows=band, async_=True)
-        hip.combine_bands(ranks, 1, band)
+        assert hip.combine_bands(ranks, 1, band) == "device-copy"      # one GPU: the packed bands are device copies
         got = ranks[1].image_read()
         assert np.array_equal(got[..., :3].view(np.uint32), full[..., :3].view(np.uint32))
+        # the root's own bands were not touched, the peers' came through pack -> one message each -> unpack
+        for r, c in enumerate(ranks):
+            c.render(sc, W, H, 32, s, rank=r, world=3, band_rows=band, async_=True)
+        assert hip.combine_bands(ranks, 0, band) == "device-copy"
+        assert np.array_equal(ranks[0].image_read()[..., :3].view(np.uint32), full[..., :3].view(np.uint32))
         with pytest.raises(hip.PtError):
             hip.combine_bands(ranks, 3, band)
         ranks[2].image_alloc(W, H + 1)
@@ -163,6 +168,21 @@ def test_combine_bands_through_the_c_abi(ctx, oracle):
     finally:
         for c in ranks:
             c.close()
+
+
+@pytest.mark.gpu
+def test_multi_process_combine_entry_points_with_one_rank(tmp_path):
+    """pt_comm_unique_id / pt_comm_init_rank / pt_combine_bands_rank with a world of one: librccl loads, every symbol
+    resolves, a communicator is created and destroyed with the context (in a child process with a time limit: a
+    communicator that cannot come up must not take the suite with it)."""
+    import sys
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from pathtracer_amd import hip\n"
+            "c = hip.Context(0); c.image_alloc(32, 16)\n"
+            "c.comm_init_rank(1, 0, hip.comm_unique_id())\n"
+            "print('transport', c.combine_bands_rank(0, 8)); c.close()\n") % ROOT
+    out = subprocess.check_output([sys.executable, "-c", code], cwd=str(tmp_path), timeout=180)
+    assert b"transport none" in out
 
 
 @pytest.mark.gpu
