@@ -63,11 +63,13 @@ PT_DEV f3 accumulate(f3 acc, f3 color, const KParams &p, int frame) {
 }
 
 // The running mean when S >= 4 lanes share a pixel (pt_render_lds_kernel): x / f1 as q = x * r, q' = fma(fma(-q, f1, x), r, q)
-// with r = RN(1 / f1).  q' is the correctly rounded quotient for EVERY significand of x and every integer f1 checked
-// (tools/probe/meandiv_probe.c: all 2^23 significands for f1 = 1 .. 65536, the top 4096 divisors below 2^24 and
-// every 4099th in between; Markstein's theorem gives it for the rest) as long as nothing under- or overflows, which
-// mean_safe() guarantees: with every colour component 0 or in [2^-40, 2^40] the mean stays in [2^-64, 2^40], x in
-// [2^-64, 2^65], and the residual is a multiple of ulp(q) >= 2^-111.
+// with r = RN(1 / f1).  q' is the correctly rounded quotient for EVERY significand of x and EVERY significand of f1:
+// both forms are invariant under powers of two in x and in f1 as long as nothing under- or overflows, so the 2^23
+// integer divisors in [2^23, 2^24) times the 2^23 significands of one binade are all cases, and tools/meandiv_walk.py
+// walked all 2^46 of them on the device's own arithmetic (pt_selftest op 12; 0 mismatches,
+// profiles/r03_meandiv_walk.json; tools/probe/meandiv_probe.c is the CPU walk of f1 = 1 .. 65536).  No under- or
+// overflow is what mean_safe() guarantees: with every colour component 0 or in [2^-40, 2^40] the mean stays in
+// [2^-64, 2^40], x in [2^-64, 2^65], and the residual is a multiple of ulp(q) >= 2^-111.
 PT_DEV bool mean_safe(f3 c) {
 	const uint32_t x = __float_as_uint(c.x), y = __float_as_uint(c.y), z = __float_as_uint(c.z);
 	const uint32_t hi = max(max(x, y), z), lo = min(min(x - 1u, y - 1u), z - 1u);      // 0 - 1 wraps to the top: 0 passes

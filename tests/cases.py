@@ -11,8 +11,10 @@ CASES = {
     "dense500_96x54": (lambda: scenes.dense_random(500), 96, 54, 50, 4),    # config 3 generator, small
     "dense3000_64x36": (lambda: scenes.dense_random(3000), 64, 36, 50, 2),
     "degenerate_64x48": (scenes.degenerate, 64, 48, 50, 8),                 # ties, duplicates, tangent / concentric spheres
-    "dense16_48x27": (lambda: scenes.dense_random(16, seed=3), 48, 27, 50, 4),     # largest table on the lock-step kernel
-    "dense17_48x27": (lambda: scenes.dense_random(17, seed=3), 48, 27, 50, 4),     # first size on the streaming kernel
+    "dense12_48x27": (lambda: scenes.dense_random(12, seed=5), 48, 27, 50, 4),     # largest open-scene table on the lock-step kernel (PT_LOCKSTEP_MAX_SPHERES)
+    "dense13_48x27": (lambda: scenes.dense_random(13, seed=5), 48, 27, 50, 4),     # first size on the streaming kernel
+    "dense16_48x27": (lambda: scenes.dense_random(16, seed=3), 48, 27, 50, 4),     # five trios + one record; a quarter chunk of the streaming scan
+    "dense17_48x27": (lambda: scenes.dense_random(17, seed=3), 48, 27, 50, 4),     # five trios + two records
     "dense512_48x27": (lambda: scenes.dense_random(512, seed=7), 48, 27, 50, 3),   # 4 chunks of 128, the last one full
     "dense513_48x27": (lambda: scenes.dense_random(513, seed=7), 48, 27, 50, 3),   # 5 chunks, the last one a single sphere
     "empty_33x17": (scenes.empty, 33, 17, 50, 3),                           # no spheres, ragged size
