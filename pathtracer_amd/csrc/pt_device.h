@@ -21,6 +21,67 @@ namespace PT_NS {
 
 struct f3 { float x, y, z; };
 
+#if PT_FAST_MATH
+// ---------------------------------------------------------------------------------------------------------------------
+// The relaxed build (pt_fast).  Its arithmetic is not "some" use of the freedoms the reference's build options grant
+// (-cl-mad-enable -cl-no-signed-zeros -cl-fast-relaxed-math, src/c/renderer.c:13) but THE use ROCm's own OpenCL
+// compiler makes of them when it builds the reference kernel for this device: every operation below is written out as
+// the reference's gfx950 code object (oracle/_ref/ptref_gfx950.hsaco, `make -C oracle ref_gfx950`) performs it — which
+// products are fused into which sums and in which order, where a divide became v_rcp_f32 and a product, where
+// v_sqrt_f32 / v_rsq_f32 are used bare, how the compiler re-associated the camera offsets and exposure * aperture, and
+// AMD's definitions of length() / normalize() / sin() / cos() from its OpenCL device library.  The translation unit is
+// compiled with -ffp-contract=off: nothing is fused or re-associated that is not written so here.  Goal and test: the
+// image equals the reference kernel's own output on this GPU BIT FOR BIT (tests/test_gpu_reference_kernel.py); what
+// stays ours is the structure around the arithmetic (all samples in one launch, LDS tables, lanes sharing a pixel,
+// wave-level culling of small spheres, the persistent streaming kernel).
+// ---------------------------------------------------------------------------------------------------------------------
+PT_DEV float ocl_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }      // v_sqrt_f32, bare (1 ulp)
+PT_DEV float ocl_rcp(float x) { return __builtin_amdgcn_rcpf(x); }        // v_rcp_f32
+PT_DEV float ocl_rsq(float x) { return __builtin_amdgcn_rsqf(x); }        // v_rsq_f32
+// x*x + y*y + z*z and a.x*b.x + a.y*b.y + a.z*b.z as the compiler fuses them: one product, two v_fmac_f32, in x, y, z order
+PT_DEV float ocl_sumsq(float x, float y, float z) { return __builtin_fmaf(z, z, __builtin_fmaf(y, y, x * x)); }
+PT_DEV float ocl_dot(f3 a, f3 b) { return __builtin_fmaf(a.z, b.z, __builtin_fmaf(a.y, b.y, a.x * b.x)); }
+// v_sqrt_f32 with the input brought into the normal range first (the compiler's expansion of sqrt for a possibly denormal input)
+PT_DEV float ocl_sqrt_scaled(float x) {
+	const bool tiny = x < 0x1p-126f;
+	const float r = ocl_sqrt(tiny ? __builtin_ldexpf(x, 32) : x);
+	return tiny ? __builtin_ldexpf(r, -16) : r;
+}
+// AMD's length(float3): sqrt of the fused sum of squares; operands re-scaled when that sum under- or overflows
+PT_DEV float ocl_length(f3 v) {
+	const float l2 = ocl_sumsq(v.x, v.y, v.z);
+	if(__builtin_expect(l2 >= 0x1p-126f, 1)) {
+		if(__builtin_expect(l2 != __builtin_inff(), 1)) return ocl_sqrt(l2);
+		return 0x1p66f * ocl_sqrt_scaled(ocl_sumsq(0x1p-66f * v.x, 0x1p-66f * v.y, 0x1p-66f * v.z));
+	}
+	return 0x1p-86f * ocl_sqrt_scaled(ocl_sumsq(0x1p86f * v.x, 0x1p86f * v.y, 0x1p86f * v.z));
+}
+// AMD's normalize(float3): v * rsq(fused sum of squares); zero vectors returned as they are, operands re-scaled when
+// the sum under- or overflows (infinite components become +-1, the others 0, as the library does)
+PT_DEV f3 ocl_normalize(f3 v) {
+	if(v.x == 0.0f && v.y == 0.0f && v.z == 0.0f) return v;
+	float l2 = ocl_sumsq(v.x, v.y, v.z);
+	if(__builtin_expect(!(l2 >= 0x1p-126f), 0)) {
+		v.x *= 0x1p86f; v.y *= 0x1p86f; v.z *= 0x1p86f;
+		l2 = ocl_sumsq(v.x, v.y, v.z);
+	} else if(__builtin_expect(l2 == __builtin_inff(), 0)) {
+		v.x *= 0x1p-66f; v.y *= 0x1p-66f; v.z *= 0x1p-66f;
+		l2 = ocl_sumsq(v.x, v.y, v.z);
+		if(l2 == __builtin_inff()) {
+			v.x = __builtin_copysignf(__builtin_isinf(v.x) ? 1.0f : 0.0f, v.x);
+			v.y = __builtin_copysignf(__builtin_isinf(v.y) ? 1.0f : 0.0f, v.y);
+			v.z = __builtin_copysignf(__builtin_isinf(v.z) ? 1.0f : 0.0f, v.z);
+			l2 = ocl_sumsq(v.x, v.y, v.z);
+		}
+	}
+	const bool tiny = l2 < 0x1p-126f;
+	float r = ocl_rsq(tiny ? l2 * 0x1p24f : l2);
+	if(tiny) r *= 0x1p12f;
+	f3 o; o.x = v.x * r; o.y = v.y * r; o.z = v.z * r;
+	return o;
+}
+#endif
+
 // The two operations whose rounding the strict build pins (correctly rounded, as the x86 oracle's) and the
 // fast build relaxes to the 1-ulp hardware instructions.
 #if PT_FAST_MATH
@@ -119,7 +180,11 @@ PT_DEV float sqrt_cr(float x) {
 	return s;
 }
 
+#if PT_FAST_MATH
+PT_DEV float len3(f3 a) { return ocl_length(a); }
+#else
 PT_DEV float len3(f3 a) { return sqrt_cr(dot3(a, a)); }
+#endif
 
 // 1.0f / x: v_rcp_f32 (1 ulp) and two FMA Newton steps, which land on the correctly rounded quotient for every x
 // with 2^-126 <= |x| <= 2^126 (pt_selftest op 5 checks all of them against the compiler's correctly rounded
@@ -162,7 +227,11 @@ PT_DEV float inv_len(float x) {
 	return r;
 #endif
 }
+#if PT_FAST_MATH
+PT_DEV f3 norm3(f3 a) { return ocl_normalize(a); }
+#else
 PT_DEV f3 norm3(f3 a) { return scl3(a, inv_len(dot3(a, a))); }
+#endif
 
 constexpr uint32_t PT_M31 = 2147483647u;   // MINSTD modulus 2^31 - 1 (src/cl/rng.cl:12)
 
@@ -196,20 +265,37 @@ PT_DEV float rand_float(uint32_t &state) {
 }
 
 // src/cl/rng.cl:16-18 with a=-1, b=1:  -1 + r*(1 - -1)
+#if PT_FAST_MATH
+PT_DEV float rand_pm1(uint32_t &state) { return __builtin_fmaf(rand_float(state), 2.0f, -1.0f); }      // v_fma_f32 r, 2.0, -1.0
+#else
 PT_DEV float rand_pm1(uint32_t &state) { return -1.0f + rand_float(state) * 2.0f; }
+#endif
 
 // src/cl/rng.cl:20-34 — theta draw first; y >= 0 always (kept: not a uniform sphere sample).
 PT_DEV f3 random_unit_vector(uint32_t &state) {
 	float cosTheta = rand_pm1(state);
 	float cosPhi = rand_pm1(state);
+#if PT_FAST_MATH
+	float sinTheta = ocl_sqrt(__builtin_fmaf(-cosTheta, cosTheta, 1.0f));      // 1 - c*c fused, bare v_sqrt_f32
+	float sinPhi = ocl_sqrt(__builtin_fmaf(-cosPhi, cosPhi, 1.0f));
+#else
 	// 1 - c*c with |c| <= 1 is 0 or >= 2^-24 (c*c is a float below 1 or exactly 1)
 	float sinTheta = sqrt_01(1.0f - cosTheta * cosTheta);
 	float sinPhi = sqrt_01(1.0f - cosPhi * cosPhi);
+#endif
 	return mk3(sinTheta * cosPhi, sinTheta * sinPhi, cosTheta);
 }
 
 // src/cl/ray.cl:54-56 — in - (normal*2)*dot(in,normal)
+#if PT_FAST_MATH
+// in - normal * 2 * dot(in, normal) as compiled: fma(-2 * n, dot, in), the dot product fused in x, y, z order
+PT_DEV f3 reflection_dir(f3 in, f3 n) {
+	const float dn = ocl_dot(in, n);
+	return mk3(__builtin_fmaf(-2.0f * n.x, dn, in.x), __builtin_fmaf(-2.0f * n.y, dn, in.y), __builtin_fmaf(-2.0f * n.z, dn, in.z));
+}
+#else
 PT_DEV f3 reflection_dir(f3 in, f3 n) { return sub3(in, scl3(scl3(n, 2.0f), dot3(in, n))); }
+#endif
 
 // pow(x,5) of oracle/ref_shim.cpp = (float)pow((double)x,5.0).  Here: x^5 in f64 (x^2 exact, two roundings
 // after) narrowed to f32.  Both are the CORRECTLY ROUNDED binary32 value of the exact x^5 for every float x:
@@ -231,13 +317,31 @@ PT_DEV float pow5(float x) {
 
 // src/cl/ray.cl:58-62 — Schlick, in two parts: r0 depends on the material only (for a front-face hit rel is the
 // sphere's refIdx, and the host folds the same four IEEE operations into the material table once)
+#if PT_FAST_MATH
+// (1 - n) / (1 + n) as v_rcp_f32(1 + n) * (1 - n); pow(x, 5) as x^2, x^4, x^4 * x; r0 + (1 - r0) * p fused
+PT_DEV float schlick_r0(float rel) {
+	const float r = ocl_rcp(1.0f + rel) * (1.0f - rel);
+	return r * r;
+}
+PT_DEV float reflectance(float cosTheta, float r0) { return __builtin_fmaf(1.0f - r0, pow5(1.0f - cosTheta), r0); }
+#else
 PT_DEV float schlick_r0(float rel) {
 	float r = pt_div(1.0f - rel, 1.0f + rel);
 	return r * r;
 }
 PT_DEV float reflectance(float cosTheta, float r0) { return r0 + (1.0f - r0) * pow5(1.0f - cosTheta); }
+#endif
 
 // src/cl/ray.cl:64-69
+#if PT_FAST_MATH
+// cosTheta is the caller's (the compiler computes the same fused chain twice and the values are equal)
+PT_DEV f3 refraction_dir(f3 in, f3 n, float rel, float cosTheta) {
+	const f3 perp = mk3(__builtin_fmaf(n.x, cosTheta, in.x) * rel, __builtin_fmaf(n.y, cosTheta, in.y) * rel, __builtin_fmaf(n.z, cosTheta, in.z) * rel);
+	const float lp = ocl_length(perp);
+	const float s = ocl_sqrt(fabsf(__builtin_fmaf(-lp, lp, 1.0f)));           // v_sqrt_f32 |1 - lp*lp|, fused
+	return mk3(perp.x - s * n.x, perp.y - s * n.y, perp.z - s * n.z);          // products rounded, then subtracted
+}
+#else
 PT_DEV f3 refraction_dir(f3 in, f3 n, float rel) {
 	float cosTheta = fminf(dot3(scl3(in, -1.0f), n), 1.0f);
 	f3 perp = scl3(add3(in, scl3(n, cosTheta)), rel);
@@ -245,5 +349,6 @@ PT_DEV f3 refraction_dir(f3 in, f3 n, float rel) {
 	f3 par = scl3(n, -sqrt_z(fabsf(1.0f - lp * lp)));       // 1 - lp*lp is 0, inf, or at least 2^-24 in magnitude
 	return add3(par, perp);
 }
+#endif
 
 }   // namespace PT_NS

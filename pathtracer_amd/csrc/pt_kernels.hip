@@ -291,7 +291,7 @@ struct pt_ctx {
 	float4 *stage; size_t capStage;
 	void *mpComm; int mpWorld, mpRank;
 	float4 *image; int imgW, imgH;
-	float4 *geom, *matA, *matB; int nSpheres, capSpheres;
+	float4 *geom, *geomR, *matA, *matB; int nSpheres, capSpheres;      // geomR: {centre, radius} for the relaxed build
 	uint64_t *seedmul; int capSeeds;
 	uint64_t *hostSeedmul; int nHostSeeds;   // what seedmul holds, to skip identical re-uploads
 	unsigned long long *counter;
@@ -370,7 +370,7 @@ extern "C" int pt_ctx_destroy(pt_ctx *c) {
 	if(!c) return PT_OK;
 	(void)hipSetDevice(c->device);
 	if(c->stream) (void)hipStreamSynchronize(c->stream);
-	(void)hipFree(c->image); (void)hipFree(c->geom); (void)hipFree(c->matA); (void)hipFree(c->matB);
+	(void)hipFree(c->image); (void)hipFree(c->geom); (void)hipFree(c->geomR); (void)hipFree(c->matA); (void)hipFree(c->matB);
 	(void)hipFree(c->seedmul); (void)hipFree(c->counter); (void)hipFree(c->queue);
 	(void)hipFree(c->dCellStart); (void)hipFree(c->dItems); (void)hipFree(c->dBig);
 	free(c->hostSpheres); (void)hipFree(c->u8); (void)hipFree(c->stage);
@@ -400,9 +400,10 @@ extern "C" int pt_scene_upload(pt_ctx *c, const float *spheres, int n) {
 	if(!c || n < 0 || (n > 0 && !spheres)) return fail(PT_E_INVALID, "pt_scene_upload: bad arguments%s", NULL);
 	HIP_TRY(hipSetDevice(c->device));
 	if(n > c->capSpheres) {
-		(void)hipFree(c->geom); (void)hipFree(c->matA); (void)hipFree(c->matB);
-		c->geom = c->matA = c->matB = NULL; c->capSpheres = 0;
+		(void)hipFree(c->geom); (void)hipFree(c->geomR); (void)hipFree(c->matA); (void)hipFree(c->matB);
+		c->geom = c->geomR = c->matA = c->matB = NULL; c->capSpheres = 0;
 		HIP_TRY(hipMalloc((void **)&c->geom, sizeof(float4) * (size_t)n));
+		HIP_TRY(hipMalloc((void **)&c->geomR, sizeof(float4) * (size_t)n));
 		HIP_TRY(hipMalloc((void **)&c->matA, sizeof(float4) * (size_t)n));
 		HIP_TRY(hipMalloc((void **)&c->matB, sizeof(float4) * (size_t)n));
 		c->capSpheres = n;
@@ -450,12 +451,13 @@ extern "C" int pt_scene_upload(pt_ctx *c, const float *spheres, int n) {
 		hb[i] = make_float4(r[8], r[9], r[10], r0);
 	}
 	// one stream, in order; the staging buffer is freed after the copies have completed
+	hipError_t e0 = hipMemcpyAsync(c->geomR, c->hostSpheres, sizeof(float4) * (size_t)n, hipMemcpyHostToDevice, c->stream);
 	hipError_t e1 = hipMemcpyAsync(c->geom, hg, sizeof(float4) * (size_t)n, hipMemcpyHostToDevice, c->stream);
 	hipError_t e2 = hipMemcpyAsync(c->matA, ha, sizeof(float4) * (size_t)n, hipMemcpyHostToDevice, c->stream);
 	hipError_t e3 = hipMemcpyAsync(c->matB, hb, sizeof(float4) * (size_t)n, hipMemcpyHostToDevice, c->stream);
 	hipError_t e4 = hipStreamSynchronize(c->stream);
 	free(h);
-	HIP_TRY(e1); HIP_TRY(e2); HIP_TRY(e3); HIP_TRY(e4);
+	HIP_TRY(e0); HIP_TRY(e1); HIP_TRY(e2); HIP_TRY(e3); HIP_TRY(e4);
 	return PT_OK;
 }
 
@@ -705,6 +707,7 @@ static int launch_frames(pt_ctx *c, const pt_render_args *a, float4 *img, hipStr
 	// cos/sin of the launch-uniform camera angles: the host libm, as the oracle uses (src/cl/ray.cl:45-49)
 	p.cosRx = cosf(a->cam_rot[0]); p.sinRx = sinf(a->cam_rot[0]);
 	p.cosRy = cosf(a->cam_rot[1]); p.sinRy = sinf(a->cam_rot[1]);
+	p.rotX = a->cam_rot[0]; p.rotY = a->cam_rot[1];
 	p.sensorWidth = a->sensor_width; p.focalLength = a->focal_length; p.aperture = a->aperture; p.exposure = a->exposure;
 	p.firstFrame = a->first_frame; p.nFrames = a->n_frames;
 	p.rank = a->rank; p.world = a->world; p.bandRows = a->band_rows;
@@ -712,7 +715,9 @@ static int launch_frames(pt_ctx *c, const pt_render_args *a, float4 *img, hipStr
 	p.localPixels = (int)lp;
 	if(lp == 0) return PT_OK;
 
-	SceneTables sc = {c->geom, c->matA, c->matB};
+	// float rules: strict (bit-identical to the oracle) unless the caller, or PT_MATH=fast, asks for the relaxed build
+	const bool fast = c->sw.math == 1 || (c->sw.math == 0 && a->fast_math != 0);
+	SceneTables sc = {fast ? c->geomR : c->geom, c->matA, c->matB};
 	LaunchPlan plan;
 	if(plan_launch(lp, a->first_frame, a->n_frames, c->sw, &plan) != PT_OK) return PT_E_INVALID;
 	p.logS = plan.logS; p.logS2 = plan.logS2;
@@ -750,9 +755,6 @@ static int launch_frames(pt_ctx *c, const pt_render_args *a, float4 *img, hipStr
 	// streaming kernel: persistent one-wave blocks, at most 32 per CU; surplus pixels come through the queue
 	const long long swaves = (lp + 63) / 64;
 	la.gridStream = (unsigned)(swaves < 256 * 32 ? swaves : 256 * 32);
-	// float rules: strict (bit-identical to the oracle) unless the caller, or PT_MATH=fast, asks for the relaxed build
-	const bool fast = c->sw.math == 1 || (c->sw.math == 0 && a->fast_math != 0);
-
 	if(la.kernel == PT_K_STREAM || la.kernel == PT_K_GRID) HIP_TRY(hipMemsetAsync(rs.queue, 0, 256, st));     // before the start event: not kernel time
 	if(a->bounce_count) {
 		HIP_TRY(hipMemsetAsync(rs.counter, 0, sizeof(unsigned long long), st));

@@ -18,6 +18,7 @@ struct KParams {
 	float bgx, bgy, bgz;
 	float px, py, pz;                   // Camera.pos
 	float cosRx, sinRx, cosRy, sinRy;   // cosf/sinf of Camera.rot.x / .y, folded on the host (rot.z is dead, src/cl/ray.cl:42-43)
+	float rotX, rotY;                   // the angles themselves: the relaxed build evaluates the device library's sin / cos, as the reference does
 	float sensorWidth, focalLength, aperture, exposure;
 	int firstFrame, nFrames;
 	int rank, world, bandRows;          // row-band partition (pt_hip.h)
@@ -27,7 +28,8 @@ struct KParams {
 	unsigned long long trioSkipMask;    // LDS kernel: bit t = trio t of the table holds a small sphere (closest_hit_lds)
 };
 
-// Device scene tables (SoA).  geom[i] = {cx, cy, cz, r*r}; matA[i] = {colr, colg, colb, type bits};
+// Device scene tables (SoA).  geom[i] = {cx, cy, cz, r*r} for the strict build, {cx, cy, cz, r} for the relaxed one (the
+// reference's code object fuses r*r into r*r - |oc|^2); matA[i] = {colr, colg, colb, type bits};
 // matB[i] = {tint, fuzz, refIdx, ((1 - refIdx) / (1 + refIdx))^2}.
 struct SceneTables {
 	const float4 *geom;

@@ -1,11 +1,12 @@
 // pt_render_kernels.h — the render kernels, compiled twice into libpt_hip.so:
 //   pt_kernels.hip       PT_NS = pt_strict, PT_FAST_MATH = 0, -ffp-contract=off -fno-fast-math
 //                        -fhip-fp32-correctly-rounded-divide-sqrt: bit-identical to the CPU oracle
-//   pt_kernels_fast.hip  PT_NS = pt_fast,   PT_FAST_MATH = 1, -ffp-contract=fast: FMA contraction,
-//                        v_sqrt_f32 / v_rcp_f32 (1 ulp) instead of correctly rounded sqrt and divide —
-//                        the freedoms the reference's own build options take
-//                        (-cl-mad-enable -cl-fast-relaxed-math, src/c/renderer.c:13); opt-in, parity
-//                        by tolerance (tests/test_gpu_fast_math.py)
+//   pt_kernels_fast.hip  PT_NS = pt_fast,   PT_FAST_MATH = 1, -ffp-contract=off as well: the arithmetic of the
+//                        reference kernel AS ROCm's OpenCL COMPILER BUILDS IT FOR gfx950 under the reference's own
+//                        options (-cl-mad-enable -cl-fast-relaxed-math, src/c/renderer.c:13), written out operation by
+//                        operation (pt_device.h): fused products, v_rcp_f32 / v_sqrt_f32 / v_rsq_f32 bare, AMD's
+//                        length() / normalize() / sin() / cos().  Opt-in; bit-identical to the reference kernel's own
+//                        output on this GPU (tests/test_gpu_reference_kernel.py), within tolerance of the oracle
 #pragma once
 #include "pt_params.h"
 #include "pt_device.h"
@@ -22,6 +23,22 @@ PT_DEV int pixel_id(const KParams &p, int t) {
 }
 
 // src/cl/main.cl:8-17 — the part of the camera ray that does not depend on the sample.
+#if PT_FAST_MATH
+// As compiled for gfx950: x / (float)W is a product with v_rcp_f32, the two offsets were re-associated to
+// ((-+2 * sensorWidth) * (float)(index - size / 2)) * rcp(W) — the aspect ratio cancelled against 1 / H —, the rotation
+// is three fused multiply-adds around rounded products, and sin / cos are the device library's (the same functions a HIP
+// translation unit gets; launch-uniform, evaluated once per pixel here).
+PT_DEV f3 camera_origin(const KParams &p, int id) {
+	const int row = id / p.W, column = id - row * p.W;
+	const float rcpW = ocl_rcp((float)p.W);
+	const float ox = ((-2.0f * p.sensorWidth) * (float)(column - p.W / 2)) * rcpW;      // -xOffset
+	const float oy = ((2.0f * p.sensorWidth) * (float)(row - p.H / 2)) * rcpW;          // yOffset
+	const float oz = p.focalLength;
+	const float cy = cosf(p.rotY), sy = sinf(p.rotY), cx = cosf(p.rotX), sx = sinf(p.rotX);
+	const f3 r = mk3(__builtin_fmaf(ox, cy, oz * sy), __builtin_fmaf(oy, cx, -(oz * sx)), __builtin_fmaf(oy, sx, oz * cx));
+	return add3(mk3(p.px, p.py, p.pz), r);
+}
+#else
 PT_DEV f3 camera_origin(const KParams &p, int id) {
 	int row = id / p.W, column = id - row * p.W;
 	float aspect = (float)p.W / (float)p.H;
@@ -32,6 +49,7 @@ PT_DEV f3 camera_origin(const KParams &p, int id) {
 	f3 r = mk3(v.x * p.cosRy + v.z * p.sinRy, v.y * p.cosRx - v.z * p.sinRx, v.y * p.sinRx + v.z * p.cosRx);
 	return add3(mk3(p.px, p.py, p.pz), r);
 }
+#endif
 
 // ---------------------------------------------------------------------------------------
 // Per-path state and the pieces every kernel variant shares
@@ -46,7 +64,12 @@ struct Path {
 PT_DEV void start_sample(Path &pt, const KParams &p, int id, f3 origin, uint64_t xb) {
 	const f3 pos = mk3(p.px, p.py, p.pz);
 	pt.rng = init_rng_2((uint32_t)id, xb);                                               // main.cl:6
+#if PT_FAST_MATH
+	const f3 ruv = random_unit_vector(pt.rng);
+	const f3 target = mk3(__builtin_fmaf(p.aperture, ruv.x, pos.x), __builtin_fmaf(p.aperture, ruv.y, pos.y), __builtin_fmaf(p.aperture, ruv.z, pos.z));
+#else
 	const f3 target = add3(pos, scl3(random_unit_vector(pt.rng), p.aperture));           // main.cl:19
+#endif
 	pt.d = norm3(sub3(target, origin));                                                  // main.cl:21
 	pt.o = pos;                                                                          // main.cl:23
 	pt.mask = mk3(1.0f, 1.0f, 1.0f);                                                     // ray.cl:93
@@ -54,10 +77,19 @@ PT_DEV void start_sample(Path &pt, const KParams &p, int id, f3 origin, uint64_t
 
 // src/cl/main.cl:27-29 — exposure scale, then the running mean with frame = f (two steps, so that lanes sharing a
 // pixel scale their own sample once and repeat only the mean)
+#if PT_FAST_MATH
+// as compiled: color * (exposure * aperture) (re-associated), then fma(image, frame, color) * v_rcp_f32(frame + 1)
+PT_DEV f3 expose(f3 color, const KParams &p) { return scl3(color, p.exposure * p.aperture); }
+PT_DEV f3 running_mean(f3 acc, f3 color, float f, float f1) {
+	const float r = ocl_rcp(f1);
+	return mk3(__builtin_fmaf(acc.x, f, color.x) * r, __builtin_fmaf(acc.y, f, color.y) * r, __builtin_fmaf(acc.z, f, color.z) * r);
+}
+#else
 PT_DEV f3 expose(f3 color, const KParams &p) { return scl3(scl3(color, p.exposure), p.aperture); }       // main.cl:27
 PT_DEV f3 running_mean(f3 acc, f3 color, float f, float f1) {                                             // main.cl:29
 	return mk3(pt_div(acc.x * f + color.x, f1), pt_div(acc.y * f + color.y, f1), pt_div(acc.z * f + color.z, f1));
 }
+#endif
 PT_DEV f3 accumulate(f3 acc, f3 color, const KParams &p, int frame) {
 	return running_mean(acc, expose(color, p), (float)frame, (float)(frame + 1));
 }
@@ -70,17 +102,74 @@ PT_DEV f3 accumulate(f3 acc, f3 color, const KParams &p, int frame) {
 // profiles/r03_meandiv_walk.json; tools/probe/meandiv_probe.c is the CPU walk of f1 = 1 .. 65536).  No under- or
 // overflow is what mean_safe() guarantees: with every colour component 0 or in [2^-40, 2^40] the mean stays in
 // [2^-64, 2^40], x in [2^-64, 2^65], and the residual is a multiple of ulp(q) >= 2^-111.
+#if PT_FAST_MATH
+PT_DEV bool mean_safe(f3) { return true; }      // the relaxed mean_step IS the relaxed running_mean: nothing to guard
+#else
 PT_DEV bool mean_safe(f3 c) {
 	const uint32_t x = __float_as_uint(c.x), y = __float_as_uint(c.y), z = __float_as_uint(c.z);
 	const uint32_t hi = max(max(x, y), z), lo = min(min(x - 1u, y - 1u), z - 1u);      // 0 - 1 wraps to the top: 0 passes
 	return hi <= 0x53800000u && lo >= 0x2B7FFFFFu;                                     // negative, NaN, inf: hi fails
 }
+#endif
+#if PT_FAST_MATH
+PT_DEV float mean_step(float acc, float c, float f, float f1, float r) { return __builtin_fmaf(acc, f, c) * r; }      // r = v_rcp_f32(f1)
+#else
 PT_DEV float mean_step(float acc, float c, float f, float f1, float r) {               // main.cl:29, one channel
 	const float x = acc * f + c;
 	const float q = x * r;
 	return __builtin_fmaf(__builtin_fmaf(-q, f1, x), r, q);
 }
+#endif
 
+#if PT_FAST_MATH
+// src/cl/ray.cl:117-171 as the reference's gfx950 code object computes it (see pt_device.h).  `g.w` is not used here.
+PT_DEV bool shade_hit(Path &pt, float t, const float4 g, const float4 mA, const float4 mB, f3 &color) {
+	const int type = __float_as_int(mA.w);
+	const f3 mcol = mk3(mA.x, mA.y, mA.z);
+	const f3 d = pt.d;
+	const f3 hitPos = mk3(__builtin_fmaf(d.x, t, pt.o.x), __builtin_fmaf(d.y, t, pt.o.y), __builtin_fmaf(d.z, t, pt.o.z));      // ray.cl:117, fused
+	f3 normal = ocl_normalize(sub3(hitPos, mk3(g.x, g.y, g.z)));                                                                // ray.cl:118
+	const f3 offPos = mk3(__builtin_fmaf(-0.0001f, normal.x, hitPos.x), __builtin_fmaf(-0.0001f, normal.y, hitPos.y),
+	                      __builtin_fmaf(-0.0001f, normal.z, hitPos.z));                                                        // ray.cl:119, fused, outward normal
+	const bool front = 0.0f >= ocl_dot(d, normal);                                                                              // ray.cl:122 as !(dot > 0)
+	if(!front) normal = mk3(-normal.x, -normal.y, -normal.z);
+	if(type <= 0) {
+		if(front && type == 0) { color = mul3(mcol, pt.mask); return true; }
+		return false;
+	}
+	if(!front && type != 3) return false;
+	f3 dir;
+	f3 mask;
+	if(type == 1) {                                                                      // ray.cl:136-141
+		const f3 ruv = random_unit_vector(pt.rng);
+		dir = add3(normal, ruv);
+		mask = mul3(mcol, pt.mask);
+	} else {
+		f3 base;
+		if(type == 2) base = reflection_dir(d, normal);                                  // ray.cl:145
+		else {                                                                           // ray.cl:150-171
+			const float cosTheta = fminf(1.0f, __builtin_fmaf(-d.z, normal.z, __builtin_fmaf(-d.y, normal.y, (-d.x) * normal.x)));
+			const float rinv = ocl_rcp(mB.z);
+			const float sinTheta = ocl_sqrt(__builtin_fmaf(-cosTheta, cosTheta, 1.0f));
+			const float rel = front ? mB.z : rinv;
+			bool reflect = 1.0f < sinTheta * rel;
+			if(!reflect) reflect = !(reflectance(cosTheta, schlick_r0(rel)) <= rand_float(pt.rng));      // short-circuit draw, ray.cl:163
+			base = reflect ? reflection_dir(d, normal) : refraction_dir(d, normal, rel, cosTheta);
+		}
+		const f3 ruv = random_unit_vector(pt.rng);
+		const float fuzz = mB.y;
+		dir = mk3(__builtin_fmaf(ruv.x, fuzz, base.x), __builtin_fmaf(ruv.y, fuzz, base.y), __builtin_fmaf(ruv.z, fuzz, base.z));
+		// mask * (1 - tint) + mask * color * tint as compiled: fma(mask, 1 - tint, (color * mask) * tint)
+		const float tint = mB.x, omt = 1.0f - tint;
+		const f3 mc = mul3(mcol, pt.mask);
+		mask = mk3(__builtin_fmaf(pt.mask.x, omt, mc.x * tint), __builtin_fmaf(pt.mask.y, omt, mc.y * tint), __builtin_fmaf(pt.mask.z, omt, mc.z * tint));
+	}
+	pt.d = dir;
+	pt.o = offPos;
+	pt.mask = mask;
+	return false;
+}
+#else
 // src/cl/ray.cl:117-171 — everything after the closest hit is known.  Returns true when the path
 // ends here (front face of a light), with its colour in `color`.
 PT_DEV bool shade_hit(Path &pt, float t, const float4 g, const float4 mA, const float4 mB, f3 &color) {
@@ -126,6 +215,7 @@ PT_DEV bool shade_hit(Path &pt, float t, const float4 g, const float4 mA, const 
 	pt.mask = mask;
 	return false;
 }
+#endif
 
 // ---------------------------------------------------------------------------------------
 // Closest hit (src/cl/ray.cl:101-110 with hit_sphere, :71-87)
@@ -174,10 +264,12 @@ constexpr uint32_t KEY_NONE = 0x7f800000u;   // bits(+inf)
 PT_DEV void sphere_disc(const float4 g, f3 o, f3 d, float a, float &bHalf, float &disc) {
 	const f3 oc = sub3(o, mk3(g.x, g.y, g.z));
 #if PT_FAST_MATH
-	// relaxed build: eight FMAs and three subtractions per test, -r^2 folded into the first product of c
-	bHalf = __builtin_fmaf(oc.z, d.z, __builtin_fmaf(oc.y, d.y, oc.x * d.x));
-	const float c = __builtin_fmaf(oc.z, oc.z, __builtin_fmaf(oc.y, oc.y, __builtin_fmaf(oc.x, oc.x, -g.w)));
-	disc = __builtin_fmaf(-a, c, bHalf * bHalf);
+	// As compiled (g.w is the RADIUS in this build's tables): b = d.x*oc.x, +oc.y*d.y, +oc.z*d.z fused in that order; the sum
+	// of squares in the order y, x, z; r*r fused into r*r - |oc|^2 = -c; disc = fma(b, b, RN(a * -c)).
+	bHalf = __builtin_fmaf(oc.z, d.z, __builtin_fmaf(oc.y, d.y, d.x * oc.x));
+	const float q = __builtin_fmaf(oc.z, oc.z, __builtin_fmaf(oc.x, oc.x, oc.y * oc.y));
+	const float negc = __builtin_fmaf(g.w, g.w, -q);
+	disc = __builtin_fmaf(bHalf, bHalf, a * negc);
 #else
 	bHalf = dot3(oc, d);
 	const float c = oc.x * oc.x + oc.y * oc.y + oc.z * oc.z - g.w;
@@ -198,11 +290,13 @@ PT_DEV void track_tiny2(float discA, float discB, float &tiny) {
 #endif
 }
 
-PT_DEV void candidate_key(float bHalf, float disc, int i, uint32_t &best, uint32_t &prev, int &idx) {
+PT_DEV void candidate_key(float bHalf, float disc, int i, uint32_t &best, uint32_t &prev, int &idx, float ra) {
 #if PT_FAST_MATH
-	// relaxed build: no tie or small-disc bookkeeping; num == +0 (t == 0, no hit) is kept out by the -1
-	const float numf = -bHalf - __builtin_amdgcn_sqrtf(disc);
-	const uint32_t keyf = __float_as_uint(numf) - 1u;
+	// relaxed build: the candidate's own distance, t = v_rcp_f32(a) * (-sqrt(disc) - b) as the reference's code object
+	// forms it, is the key — the strict `<` of ray.cl:104 on the very floats the reference compares, lowest index first.
+	// t > 0 (ray.cl:82) <=> bits(t) - 1 < bits(+inf); a negative disc gives a NaN t, which is no hit (ray.cl:78).
+	const float tf = ra * (-__builtin_amdgcn_sqrtf(disc) - bHalf);
+	const uint32_t keyf = __float_as_uint(tf) - 1u;
 	const bool updf = keyf < best;
 	idx = updf ? i : idx;
 	best = updf ? keyf : best;
@@ -216,15 +310,16 @@ PT_DEV void candidate_key(float bHalf, float disc, int i, uint32_t &best, uint32
 	best = upd ? key : best;
 }
 
-PT_DEV void candidate_update(float bHalf, float disc, int i, uint32_t &best, uint32_t &prev, int &idx, float &tiny) {
+PT_DEV void candidate_update(float bHalf, float disc, int i, uint32_t &best, uint32_t &prev, int &idx, float &tiny, float ra) {
 	track_tiny(disc, tiny);
-	candidate_key(bHalf, disc, i, best, prev, idx);
+	candidate_key(bHalf, disc, i, best, prev, idx, ra);
 }
 
-PT_DEV void test_sphere(const float4 g, int i, f3 o, f3 d, float a, uint32_t &best, uint32_t &prev, int &idx, float &tiny) {
+// `ra`: v_rcp_f32(a), used by the relaxed build only (its keys are the distances themselves)
+PT_DEV void test_sphere(const float4 g, int i, f3 o, f3 d, float a, uint32_t &best, uint32_t &prev, int &idx, float &tiny, float ra) {
 	float bHalf, disc;
 	sphere_disc(g, o, d, a, bHalf, disc);
-	candidate_update(bHalf, disc, i, best, prev, idx, tiny);
+	candidate_update(bHalf, disc, i, best, prev, idx, tiny, ra);
 }
 
 // "This lane can hit the sphere" as a sign bit: disc >= 0 and bHalf < 0, i.e. sign(disc) clear and sign(bHalf) set, in
@@ -240,7 +335,7 @@ PT_DEV int can_hit(float bHalf, float disc) { return (int)(~__float_as_uint(disc
 // is possible): can_hit(); what is skipped is no hit in the
 // reference either (disc < 0: ray.cl:78; bHalf >= 0: t <= 0).  count4 is a multiple of 4; the chunk is
 // padded with spheres of r^2 = -inf, whose disc is -inf.
-PT_DEV void scan_chunk(const float4 *buf, int count4, int base, f3 o, f3 d, float a, uint32_t &best, uint32_t &prev, int &idx, float &tiny) {
+PT_DEV void scan_chunk(const float4 *buf, int count4, int base, f3 o, f3 d, float a, float ra, uint32_t &best, uint32_t &prev, int &idx, float &tiny) {
 	for(int i = 0; i < count4; i += 4) {
 		const float4 g0 = buf[i], g1 = buf[i + 1], g2 = buf[i + 2], g3 = buf[i + 3];
 		float b0, b1, b2, b3, d0, d1, d2, d3;
@@ -250,10 +345,10 @@ PT_DEV void scan_chunk(const float4 *buf, int count4, int base, f3 o, f3 d, floa
 		sphere_disc(g3, o, d, a, b3, d3);
 		const int m0 = can_hit(b0, d0), m1 = can_hit(b1, d1), m2 = can_hit(b2, d2), m3 = can_hit(b3, d3);
 		if(__builtin_amdgcn_ballot_w64((m0 | m1 | m2 | m3) < 0) != 0) {
-			if(__builtin_amdgcn_ballot_w64(m0 < 0) != 0) candidate_update(b0, d0, base + i, best, prev, idx, tiny);
-			if(__builtin_amdgcn_ballot_w64(m1 < 0) != 0) candidate_update(b1, d1, base + i + 1, best, prev, idx, tiny);
-			if(__builtin_amdgcn_ballot_w64(m2 < 0) != 0) candidate_update(b2, d2, base + i + 2, best, prev, idx, tiny);
-			if(__builtin_amdgcn_ballot_w64(m3 < 0) != 0) candidate_update(b3, d3, base + i + 3, best, prev, idx, tiny);
+			if(__builtin_amdgcn_ballot_w64(m0 < 0) != 0) candidate_update(b0, d0, base + i, best, prev, idx, tiny, ra);
+			if(__builtin_amdgcn_ballot_w64(m1 < 0) != 0) candidate_update(b1, d1, base + i + 1, best, prev, idx, tiny, ra);
+			if(__builtin_amdgcn_ballot_w64(m2 < 0) != 0) candidate_update(b2, d2, base + i + 2, best, prev, idx, tiny, ra);
+			if(__builtin_amdgcn_ballot_w64(m3 < 0) != 0) candidate_update(b3, d3, base + i + 3, best, prev, idx, tiny, ra);
 		}
 	}
 }
@@ -273,8 +368,7 @@ PT_DEV Hit finish_scan(float a, float rinv, uint32_t best, uint32_t prev, int id
 	h.hit = best < KEY_NONE;
 	h.idx = idx;
 #if PT_FAST_MATH
-	h.hit = best < KEY_NONE - 1u;
-	h.t = __uint_as_float(best + 1u) * rinv;
+	h.t = __uint_as_float(best + 1u);      // the key IS the winner's distance (candidate_key)
 	slow = false;
 	return h;
 #endif
@@ -308,7 +402,11 @@ PT_DEV Hit closest_hit_wave(const float4 *__restrict__ geom, int n, f3 o, f3 d, 
 	for(int i = lane; i < n; i += 64) {
 		float bHalf, disc;
 		sphere_disc(geom[i], o, d, a, bHalf, disc);
+#if PT_FAST_MATH
+		const float t = ocl_rcp(a) * (-ocl_sqrt(disc) - bHalf);      // as the reference's code object forms it (candidate_key)
+#else
 		const float t = (-bHalf - sqrtf(disc)) / a;      // disc < 0 (ray.cl:78): sqrtf gives NaN, t is NaN, no hit
+#endif
 		const uint32_t key = __float_as_uint(t) - 1u;
 		if(key < bk) { bk = key; bi = i; }
 	}
@@ -372,7 +470,7 @@ PT_DEV bool wave_can_hit(float disc, float bHalf) {
 // is rarely a candidate for any of the 64 rays of a wave, and its sqrt/select part is entered only if it is.
 // One trio of the lock-step scan (closest_hit_lds)
 template <bool SKIP>
-PT_DEV void scan_trio(uint32_t addr, bool skipBit, f3 o, f3 d, float a, uint32_t &best, uint32_t &prev, int &idx, float &tiny) {
+PT_DEV void scan_trio(uint32_t addr, bool skipBit, f3 o, f3 d, float a, float ra, uint32_t &best, uint32_t &prev, int &idx, float &tiny) {
 	const float4 g0 = lds_f4(addr), g1 = lds_f4(addr + PT_REC_BYTES), g2 = lds_f4(addr + 2 * PT_REC_BYTES);
 	const int4 ii = lds_i4(addr + 3 * PT_REC_BYTES);
 	float b0, b1, b2, d0, d1, d2;
@@ -382,18 +480,20 @@ PT_DEV void scan_trio(uint32_t addr, bool skipBit, f3 o, f3 d, float a, uint32_t
 	if(SKIP && skipBit) {
 		// (the empty asm keeps the compiler from flattening the branch into "compute the root anyway and select": it
 		// did that to the relaxed build's short update, 65.9 -> 68.5 ms on the 39-sphere lattice)
-		if(wave_can_hit(d0, b0)) { asm volatile(""); candidate_update(b0, d0, ii.x, best, prev, idx, tiny); }
-		if(wave_can_hit(d1, b1)) { asm volatile(""); candidate_update(b1, d1, ii.y, best, prev, idx, tiny); }
-		if(wave_can_hit(d2, b2)) { asm volatile(""); candidate_update(b2, d2, ii.z, best, prev, idx, tiny); }
+		if(wave_can_hit(d0, b0)) { asm volatile(""); candidate_update(b0, d0, ii.x, best, prev, idx, tiny, ra); }
+		if(wave_can_hit(d1, b1)) { asm volatile(""); candidate_update(b1, d1, ii.y, best, prev, idx, tiny, ra); }
+		if(wave_can_hit(d2, b2)) { asm volatile(""); candidate_update(b2, d2, ii.z, best, prev, idx, tiny, ra); }
 	} else {
 		track_tiny2(d0, d1, tiny);
 		track_tiny(d2, tiny);
-		candidate_key(b0, d0, ii.x, best, prev, idx);
-		candidate_key(b1, d1, ii.y, best, prev, idx);
-		candidate_key(b2, d2, ii.z, best, prev, idx);
+		candidate_key(b0, d0, ii.x, best, prev, idx, ra);
+		candidate_key(b1, d1, ii.y, best, prev, idx, ra);
+		candidate_key(b2, d2, ii.z, best, prev, idx, ra);
 	}
 }
 
+// `ya`: strict build v_rsq_f32(dot(d, d)) (its square seeds the one divide); relaxed build v_rcp_f32(a), handed to every
+// candidate (candidate_key).
 // NT > 0: the table has exactly NT trios and no remainder (n == 3 * NT) and the small-sphere mask is the compile-time
 // constant MASK: the scan is straight-line code, which spares the loop-carried register copies (4 per trio) and the
 // merges of the two forms of a trio, and lets the compiler keep the first trio in registers across bounces (the
@@ -410,7 +510,7 @@ PT_DEV Hit closest_hit_lds(uint32_t base, int n, unsigned long long skipMask, f3
 	if(NT > 0) {
 		skipMask = (unsigned long long)MASK;      // a compile-time constant from here on
 #pragma unroll
-		for(int t = 0; t < NT; t++) scan_trio<SKIP>(base + PT_TRIO_BYTES * t, SKIP && ((skipMask >> t) & 1u), o, d, a, best, prev, idx, tiny);
+		for(int t = 0; t < NT; t++) scan_trio<SKIP>(base + PT_TRIO_BYTES * t, SKIP && ((skipMask >> t) & 1u), o, d, a, ya, best, prev, idx, tiny);
 		i = n;
 	} else if(SKIP) {
 		// the mask as RUNS of trios of one form, each run a loop of its own: a loop body that holds both forms pays for
@@ -419,20 +519,20 @@ PT_DEV Hit closest_hit_lds(uint32_t base, int n, unsigned long long skipMask, f3
 		while(left > 0) {
 			int run = skipMask ? __builtin_ctzll(skipMask) : 64;               // trios without a small sphere
 			run = run < left ? run : left;
-			for(int j = 0; j < run; j++, addr += PT_TRIO_BYTES) scan_trio<false>(addr, false, o, d, a, best, prev, idx, tiny);
+			for(int j = 0; j < run; j++, addr += PT_TRIO_BYTES) scan_trio<false>(addr, false, o, d, a, ya, best, prev, idx, tiny);
 			left -= run;
 			skipMask = run < 64 ? skipMask >> run : 0ull;
 			run = ~skipMask ? __builtin_ctzll(~skipMask) : 64;                    // trios with one
 			run = run < left ? run : left;
-			for(int j = 0; j < run; j++, addr += PT_TRIO_BYTES) scan_trio<true>(addr, true, o, d, a, best, prev, idx, tiny);
+			for(int j = 0; j < run; j++, addr += PT_TRIO_BYTES) scan_trio<true>(addr, true, o, d, a, ya, best, prev, idx, tiny);
 			left -= run;
 			skipMask = run < 64 ? skipMask >> run : 0ull;
 		}
 		i = 3 * (n / 3);
 	} else {
-		for(; i + 3 <= n; i += 3, addr += PT_TRIO_BYTES) scan_trio<false>(addr, false, o, d, a, best, prev, idx, tiny);
+		for(; i + 3 <= n; i += 3, addr += PT_TRIO_BYTES) scan_trio<false>(addr, false, o, d, a, ya, best, prev, idx, tiny);
 	}
-	for(; i < n; i++, addr += PT_REC_BYTES) test_sphere(lds_f4(addr), (int)addr, o, d, a, best, prev, idx, tiny);
+	for(; i < n; i++, addr += PT_REC_BYTES) test_sphere(lds_f4(addr), (int)addr, o, d, a, best, prev, idx, tiny, ya);
 	bool slow;
 	Hit h = finish_scan(a, ya * ya, best, prev, idx, tiny, slow);      // ya = v_rsq_f32(dot(d, d)): ya^2 seeds 1 / a (div_by_a)
 	if(__builtin_expect(slow, 0)) {
@@ -518,8 +618,9 @@ __global__ PT_LDS_BOUNDS void pt_render_lds_kernel(float4 *__restrict__ image, c
 				for(int j = 0; j < p.maxDepth; j++) {                                    // ray.cl:96
 					if(COUNT) myBounces++;
 #if PT_FAST_MATH
-					// relaxed build: pow(length(d), 2) as dot(d, d); closest_hit_lds() squares its last argument for 1 / a
-					const float a = dot3(pt.d, pt.d), ya = __builtin_amdgcn_rsqf(a);
+					// as compiled: length(d) = v_sqrt_f32 of the fused sum of squares, a = len * len, 1 / a = v_rcp_f32(a)
+					const float ln = ocl_length(pt.d);
+					const float a = ln * ln, ya = ocl_rcp(a);
 #else
 					float ya;
 					const float ln = sqrt_pos_y(dot3(pt.d, pt.d), ya);                   // see closest_hit_lds()
@@ -591,7 +692,11 @@ PT_DEV void grid_test(const float4 *__restrict__ geom, int i, f3 o, f3 d, float 
 	float bHalf, disc;
 	sphere_disc(geom[i], o, d, a, bHalf, disc);
 	if(!(disc < 0.0f)) {                                               // ray.cl:78
+#if PT_FAST_MATH
+		const float t = ocl_rcp(a) * (-ocl_sqrt(disc) - bHalf);
+#else
 		const float t = pt_div(-bHalf - sqrt_cr(disc), a);             // ray.cl:80 (sqrt_cr == sqrtf, pt_device.h)
+#endif
 		const uint32_t key = __float_as_uint(t) - 1u;                  // t > 0 (ray.cl:82) <=> key < bits(+inf)
 		if(key < bk || (key == bk && i < bi)) { bk = key; bi = i; }
 	}
@@ -687,7 +792,9 @@ PT_DEV Hit closest_hit_grid(const GridTables &G, const float4 *__restrict__ geom
 // ---------------------------------------------------------------------------------------
 #define PT_CHUNK 128
 #define PT_COOP_MAX_LANES 16   // at or below this many tracing lanes the wave scans ray by ray, 64 spheres per step
-#define PT_PAD_SPHERE make_float4(0.0f, 0.0f, 0.0f, -__builtin_inff())   // r^2 = -inf: disc = -inf, never a candidate
+// strict build: r^2 = -inf, disc = -inf, never a candidate.  Relaxed build (w is the radius): -c = +inf, disc = +inf,
+// t = rcp(a) * (-inf - b) = -inf: no hit either.
+#define PT_PAD_SPHERE make_float4(0.0f, 0.0f, 0.0f, -__builtin_inff())
 
 template <bool COUNT, bool GRID>
 __global__ __launch_bounds__(64) void pt_render_stream_kernel(float4 *__restrict__ image, const KParams p, const SceneTables sc,
@@ -744,11 +851,12 @@ __global__ __launch_bounds__(64) void pt_render_stream_kernel(float4 *__restrict
 		}
 		// ---- one bounce of every lane that owns a pixel
 		const bool tracing = has && j < p.maxDepth;                                      // ray.cl:96
-		float a = 1.0f;
+		float a = 1.0f, rcpA = 1.0f;
 		if(tracing) {
 			if(COUNT) myBounces++;
 			const float ln = len3(pt.d);
 			a = ln * ln;                                                                 // ray.cl:73
+			rcpA = __builtin_amdgcn_rcpf(a);      // strict build: seed of finish_scan's divide; relaxed build: the reference's 1 / a
 		}
 		Hit h;
 		h.hit = false; h.t = 0.0f; h.idx = 0;
@@ -779,7 +887,7 @@ __global__ __launch_bounds__(64) void pt_render_stream_kernel(float4 *__restrict
 				if(tracing) {
 					const int left = p.n - c * PT_CHUNK;
 					const int count4 = left >= PT_CHUNK ? PT_CHUNK : ((left + 3) & ~3);
-					scan_chunk(sChunk[c & 1], count4, c * PT_CHUNK, pt.o, pt.d, a, best, prev, idx, tiny);
+					scan_chunk(sChunk[c & 1], count4, c * PT_CHUNK, pt.o, pt.d, a, rcpA, best, prev, idx, tiny);
 				}
 				if(more) {
 					sChunk[(c + 1) & 1][lane] = r0;
@@ -788,7 +896,7 @@ __global__ __launch_bounds__(64) void pt_render_stream_kernel(float4 *__restrict
 				if(nchunks > 1) __syncthreads();
 			}
 			bool slow = false;
-			if(tracing) h = finish_scan(a, __builtin_amdgcn_rcpf(a), best, prev, idx, tiny, slow);
+			if(tracing) h = finish_scan(a, rcpA, best, prev, idx, tiny, slow);
 			coop = __builtin_amdgcn_ballot_w64(slow);
 		}
 		// sphere-parallel: the wave takes the remaining rays one at a time, with the reference's arithmetic

@@ -67,7 +67,8 @@ def main():
             h = him[..., :3]
             d = np.abs(h.astype(np.float64) - rgb).max(axis=-1)
             key = "hip_fast" if fast else "hip_strict"
-            res[key] = dict(kernel_ms=ms, share_1e4=float((d <= 1e-4).mean()), share_1e3=float((d <= 1e-3).mean()), share_1e2=float((d <= 1e-2).mean()),
+            same = (np.ascontiguousarray(h).view(np.uint32) == rgb.view(np.uint32)).all(axis=-1)
+            res[key] = dict(kernel_ms=ms, pixels=int(same.size), pixels_differing_in_bits=int((~same).sum()), share_1e4=float((d <= 1e-4).mean()), share_1e3=float((d <= 1e-3).mean()), share_1e2=float((d <= 1e-2).mean()),
                             off_1e4=int((d > 1e-4).sum()), max_abs=float(d.max()), psnr_u8=envelope.psnr_u8(h_u8, r_u8),
                             u8_equal_share=float((h_u8 == r_u8).all(axis=-1).mean()),
                             u8_max_diff=int(np.abs(h_u8.astype(np.int32) - r_u8.astype(np.int32)).max()),

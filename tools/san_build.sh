@@ -13,7 +13,7 @@ for f in renderer pt_image_io scene_driver; do
 done
 H="--offload-arch=gfx950 -O3 -fno-slp-vectorize -std=c++17 $INC -Xarch_host -fsanitize=address -Xarch_host -fsanitize=undefined -Xarch_host -g"
 hipcc $H -ffp-contract=off -fno-fast-math -fhip-fp32-correctly-rounded-divide-sqrt -c pathtracer_amd/csrc/pt_kernels.hip -o build/san/k.o
-hipcc $H -ffp-contract=fast -c pathtracer_amd/csrc/pt_kernels_fast.hip -o build/san/kf.o
+hipcc $H -ffp-contract=off -c pathtracer_amd/csrc/pt_kernels_fast.hip -o build/san/kf.o
 hipcc --offload-arch=gfx950 -fsanitize=address -fsanitize=undefined -fno-gpu-sanitize build/san/scene_driver.o build/san/renderer.o \
 	build/san/pt_image_io.o build/san/k.o build/san/kf.o -o build/san/pt_scene_driver_san -ldl -lm -lpthread
 rm -f build/san/*.o
