@@ -47,36 +47,51 @@ PT_DEV float ocl_sqrt_scaled(float x) {
 	const float r = ocl_sqrt(tiny ? __builtin_ldexpf(x, 32) : x);
 	return tiny ? __builtin_ldexpf(r, -16) : r;
 }
+// FLT_MIN <= x < +inf in one unsigned compare (NaN, negative, zero, denormal and infinite x fail it)
+PT_DEV bool ocl_plain(float x) { return __float_as_uint(x) - 0x00800000u < 0x7f000000u; }
 // AMD's length(float3): sqrt of the fused sum of squares; operands re-scaled when that sum under- or overflows
+// (the rare path: ocl_length_edge)
+PT_DEV float ocl_length_edge(float x, float y, float z, float l2) {
+	if(l2 >= 0x1p-126f) {
+		if(l2 != __builtin_inff()) return ocl_sqrt(l2);
+		return 0x1p66f * ocl_sqrt_scaled(ocl_sumsq(0x1p-66f * x, 0x1p-66f * y, 0x1p-66f * z));
+	}
+	return 0x1p-86f * ocl_sqrt_scaled(ocl_sumsq(0x1p86f * x, 0x1p86f * y, 0x1p86f * z));
+}
 PT_DEV float ocl_length(f3 v) {
 	const float l2 = ocl_sumsq(v.x, v.y, v.z);
-	if(__builtin_expect(l2 >= 0x1p-126f, 1)) {
-		if(__builtin_expect(l2 != __builtin_inff(), 1)) return ocl_sqrt(l2);
-		return 0x1p66f * ocl_sqrt_scaled(ocl_sumsq(0x1p-66f * v.x, 0x1p-66f * v.y, 0x1p-66f * v.z));
-	}
-	return 0x1p-86f * ocl_sqrt_scaled(ocl_sumsq(0x1p86f * v.x, 0x1p86f * v.y, 0x1p86f * v.z));
+	if(__builtin_expect(ocl_plain(l2), 1)) return ocl_sqrt(l2);
+	return ocl_length_edge(v.x, v.y, v.z, l2);
 }
 // AMD's normalize(float3): v * rsq(fused sum of squares); zero vectors returned as they are, operands re-scaled when
-// the sum under- or overflows (infinite components become +-1, the others 0, as the library does)
-PT_DEV f3 ocl_normalize(f3 v) {
-	if(v.x == 0.0f && v.y == 0.0f && v.z == 0.0f) return v;
-	float l2 = ocl_sumsq(v.x, v.y, v.z);
-	if(__builtin_expect(!(l2 >= 0x1p-126f), 0)) {
-		v.x *= 0x1p86f; v.y *= 0x1p86f; v.z *= 0x1p86f;
-		l2 = ocl_sumsq(v.x, v.y, v.z);
-	} else if(__builtin_expect(l2 == __builtin_inff(), 0)) {
-		v.x *= 0x1p-66f; v.y *= 0x1p-66f; v.z *= 0x1p-66f;
-		l2 = ocl_sumsq(v.x, v.y, v.z);
+// the sum under- or overflows (infinite components become +-1, the others 0, as the library does) — the rare path;
+// returns the factor and may replace the components
+PT_DEV float ocl_normalize_edge(float &x, float &y, float &z) {
+	if(x == 0.0f && y == 0.0f && z == 0.0f) return 1.0f;
+	float l2 = ocl_sumsq(x, y, z);
+	if(!(l2 >= 0x1p-126f)) {
+		x *= 0x1p86f; y *= 0x1p86f; z *= 0x1p86f;
+		l2 = ocl_sumsq(x, y, z);
+	} else if(l2 == __builtin_inff()) {
+		x *= 0x1p-66f; y *= 0x1p-66f; z *= 0x1p-66f;
+		l2 = ocl_sumsq(x, y, z);
 		if(l2 == __builtin_inff()) {
-			v.x = __builtin_copysignf(__builtin_isinf(v.x) ? 1.0f : 0.0f, v.x);
-			v.y = __builtin_copysignf(__builtin_isinf(v.y) ? 1.0f : 0.0f, v.y);
-			v.z = __builtin_copysignf(__builtin_isinf(v.z) ? 1.0f : 0.0f, v.z);
-			l2 = ocl_sumsq(v.x, v.y, v.z);
+			x = __builtin_copysignf(__builtin_isinf(x) ? 1.0f : 0.0f, x);
+			y = __builtin_copysignf(__builtin_isinf(y) ? 1.0f : 0.0f, y);
+			z = __builtin_copysignf(__builtin_isinf(z) ? 1.0f : 0.0f, z);
+			l2 = ocl_sumsq(x, y, z);
 		}
 	}
 	const bool tiny = l2 < 0x1p-126f;
 	float r = ocl_rsq(tiny ? l2 * 0x1p24f : l2);
 	if(tiny) r *= 0x1p12f;
+	return r;
+}
+PT_DEV f3 ocl_normalize(f3 v) {
+	const float l2 = ocl_sumsq(v.x, v.y, v.z);
+	float r;
+	if(__builtin_expect(ocl_plain(l2), 1)) r = ocl_rsq(l2);
+	else r = ocl_normalize_edge(v.x, v.y, v.z);
 	f3 o; o.x = v.x * r; o.y = v.y * r; o.z = v.z * r;
 	return o;
 }
