@@ -7,6 +7,13 @@ reference's render() would run (src/c/renderer.c:153-262).  One step = one whole
 image: W*H*spp samples.  Scene, seeds and accumulator are resident on the GPU when the timed
 region starts; the per-step host->device traffic is the 2 KB seed table.
 
+What is timed is the build the drop-in runs by default (renderer.c): the reference kernel's own
+arithmetic as its OpenCL build for gfx950 performs it (pt_render_args.fast_math = 1).
+After the timed region EVERY pixel of the last frame is compared, in bits, with the frame the
+reference kernel itself (oracle/_ref/ptref_gfx950.hsaco through tests/gpuref.py, the checker) renders
+on this GPU from the same scene and seeds.  The strict-IEEE build (bit-identical to the CPU oracle,
+rows checked against it) is measured beside it, untimed, as `strict_build`.
+
 N = 1 : python bench.py [--steps K --warmup W]
 N > 1 : python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N
         one process per GPU; the SAME image is cut into 8-row bands dealt round-robin to the ranks
@@ -97,13 +104,33 @@ def verify_frame(frame_rows, scene, seeds, rows):
     return len(rows)
 
 
+def verify_against_reference_kernel(frame, scene, seeds, W, H, depth):
+    """Every pixel of `frame` ([H, W, 4] numpy) against the reference kernel's own render of the same scene and seeds on
+    this GPU, bit for bit.  Checker only, after the timed region.  Returns a description, or None when the code object
+    is not in the tree (it is built only where /root/reference exists)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import gpuref
+    if not gpuref.available():
+        return None
+    k = gpuref.ReferenceKernel()
+    try:
+        want = k.render(scene, W, H, depth, seeds)[..., :3]
+    finally:
+        k.close()
+    got = np.ascontiguousarray(frame[..., :3])
+    diff = int((got.view(np.uint32) != np.ascontiguousarray(want).view(np.uint32)).any(axis=-1).sum())
+    if diff:
+        raise SystemExit("bench.py: %d pixels of the benchmarked frame differ in bits from the reference kernel's frame" % diff)
+    return "all %d pixels bit-identical to the reference kernel's own frame on this GPU (%d launches of its gfx950 code object)" % (W * H, len(seeds))
+
+
 def measured_traffic():
     """HBM bytes per launch of the dominant kernel from the newest PMC summary of it in profiles/ (WRITE_SIZE + FETCH_SIZE,
     KiB per dispatch as rocprofv3 reports them; the table is read from LDS and the reads are not wide streaming loads, so no
     x2 correction applies to the 0.05-0.1 MB that are fetched).  Returns (bytes, file) or (None, None)."""
     import glob
     import re
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_lds_strict*.md")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_lds_fast*.md")))
     for f in reversed(files):
         text = open(f).read()
         w = re.search(r"\|\s*WRITE_SIZE\s*\|\s*([0-9.e+]+)", text)
@@ -113,12 +140,16 @@ def measured_traffic():
     return None, None
 
 
-def extras(ctx, stream, torch, hip, scenes, seedmod, budget_s=60.0):
-    """The other BASELINE configs on this GPU (after the timed loop, rank 0, N = 1): kernel time from HIP events (mean of
-    two warm launches), bounces per sample counted in-kernel, the roofline fraction by the same SURVEY.md §8d formula,
-    and a handful of pixels of each frame checked against the CPU oracle at the full sample count, bit for bit."""
+def extras(ctx, stream, torch, hip, scenes, seedmod, budget_s=90.0):
+    """The other BASELINE configs on this GPU (after the timed loop, rank 0, N = 1), both builds: kernel time from HIP
+    events (mean of two warm launches), bounces per sample counted in-kernel, the roofline fraction by the same
+    SURVEY.md §8d formula.  Checks, untimed: the reference-exact build's frame of the first two samples against the
+    reference kernel's own (every pixel, in bits; live, tests/gpuref.py), and pixels of the strict build's full frame
+    against the CPU oracle at the full sample count, bit for bit."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import gpuref
     import oracle_lib
+    from pathtracer_amd import partition
     oracle = oracle_lib.load_oracle()
     threads = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16") or 16))
     dev = torch.device("cuda", torch.cuda.current_device())
@@ -128,7 +159,7 @@ def extras(ctx, stream, torch, hip, scenes, seedmod, budget_s=60.0):
         ("configs[3]: frame-0 scene 3840x2160 1024 spp, rank 3 of 8 (8-row bands)", "pt_render_lds_kernel", lambda: scenes.main_lua_frame(0), 3840, 2160, 1024, 50, 8, 3, ((24 * 8 + 3) * 8 * 3840 + 1900, 8)),
         ("configs[4]: glass lattice + emitters (39 spheres) 1920x1080 64 spp depth 32", "pt_render_lds_kernel (scan loop)", scenes.glass_lattice, 1920, 1080, 64, 32, 1, 0, (500 * 1920 + 900, 64)),
     ]
-    from pathtracer_amd import partition
+    refk = gpuref.ReferenceKernel() if gpuref.available() else None
     out, t_begin = [], time.perf_counter()
     for label, kernel, factory, W, H, spp, depth, world, rank, probe in cases:
         if time.perf_counter() - t_begin > budget_s:
@@ -140,32 +171,48 @@ def extras(ctx, stream, torch, hip, scenes, seedmod, budget_s=60.0):
         ctx.scene_upload(sc["spheres"])
         frame = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)
         kw = dict(rank=rank, world=world, band_rows=BAND_ROWS, d_image=frame.data_ptr(), stream=stream, async_=True)
-        bounces = ctx.render(sc, W, H, depth, s, count_bounces=True, **{k: v for k, v in kw.items() if k != "async_"})
-        for fast in (False, True):
+        sync_kw = {k: v for k, v in kw.items() if k != "async_"}
+        bounces = ctx.render(sc, W, H, depth, s, count_bounces=True, fast_math=True, **sync_kw)
+        for fast in (True, False):
             for _ in range(3):
                 ctx.render(sc, W, H, depth, s, record_timing=True, fast_math=fast, **kw)
         torch.cuda.synchronize()
         kt = ctx.kernel_times()
-        ms, fast_ms = float(np.mean(kt[1:3])), float(np.mean(kt[4:6]))
-        ctx.render(sc, W, H, depth, s, **kw)                  # the strict build's frame, for the check below
-        torch.cuda.synchronize()
+        ms, strict_ms = float(np.mean(kt[1:3])), float(np.mean(kt[4:6]))
         samples = partition.local_pixel_count(W, H, rank, world, BAND_ROWS) * spp
         bps = bounces / samples
         fps = flops_per_sample(bps, n)
+        # the strict build's frame (left by the last timed launch) against the oracle
         b, cnt = probe if probe else (0, W * H)
         want = oracle.render(sc, W, H, depth, s, id_begin=b, id_end=b + cnt, nthreads=threads).reshape(-1, 4)[b:b + cnt, :3]
         got = frame.reshape(-1, 4)[b:b + cnt, :3].cpu().numpy()
         if not np.array_equal(np.ascontiguousarray(got).view(np.uint32), np.ascontiguousarray(want).view(np.uint32)):
-            raise SystemExit("bench.py extras: %s: pixels %d..%d differ from the oracle" % (label, b, b + cnt))
+            raise SystemExit("bench.py extras: %s: pixels %d..%d of the strict build differ from the oracle" % (label, b, b + cnt))
+        # the reference-exact build against the reference kernel: the first two samples of every pixel this rank owns
+        checked_ref = "reference code object not in the tree"
+        if refk is not None:
+            k2 = min(spp, 2)
+            frame.zero_()
+            ctx.render(sc, W, H, depth, s[:k2], fast_math=True, **sync_kw)
+            mine = frame[..., :3].cpu().numpy()
+            ref = refk.render(sc, W, H, depth, s[:k2])[..., :3]
+            rows = partition.rows_of_rank(H, rank, world, BAND_ROWS)
+            diff = int((np.ascontiguousarray(mine[rows]).view(np.uint32) != np.ascontiguousarray(ref[rows]).view(np.uint32)).any(axis=-1).sum())
+            if diff:
+                raise SystemExit("bench.py extras: %s: %d pixels differ in bits from the reference kernel's frame" % (label, diff))
+            checked_ref = "all %d pixels of this rank bit-identical to the reference kernel's frame at the first %d samples" % (len(rows) * W, k2)
         e = {"workload": label, "spheres": int(n), "kernel": kernel,
              "kernel_ms": ms, "msamples_s": samples / ms / 1e3, "bounces_per_sample": round(bps, 3),
              "frac": fps * samples / (ms * 1e-3) / 1e12 / PEAK_FP32_VALU_TFLOPS,
-             "fast_math_kernel_ms": fast_ms, "fast_math_frac": fps * samples / (fast_ms * 1e-3) / 1e12 / PEAK_FP32_VALU_TFLOPS,
-             "checked_pixels": int(cnt), "checked": "pixels %d..%d bit-identical to the CPU oracle at %d spp" % (b, b + cnt - 1, spp)}
+             "checked": checked_ref,
+             "strict_build_kernel_ms": strict_ms, "strict_build_frac": fps * samples / (strict_ms * 1e-3) / 1e12 / PEAK_FP32_VALU_TFLOPS,
+             "strict_build_checked": "pixels %d..%d bit-identical to the CPU oracle at %d spp" % (b, b + cnt - 1, spp)}
         if n >= 1000:
             e["gtests_s"] = samples * bps * n / (ms * 1e-3) / 1e9      # ray-sphere tests per second
         out.append(e)
         del frame
+    if refk is not None:
+        refk.close()
     return out
 
 
@@ -176,7 +223,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true", help="skip the oracle check of the benchmarked frame (about 3 s of CPU)")
-    ap.add_argument("--no-fast-math", action="store_true", help="skip the extra, untimed measurement of the relaxed-float build")
+    ap.add_argument("--no-strict", "--no-fast-math", dest="no_strict", action="store_true",
+                    help="skip the extra, untimed measurement of the strict-IEEE build")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed measurements of the other BASELINE configs (about 20 s)")
     ap.add_argument("--combine", choices=("product", "torch"), default="product",
                     help="N > 1: the product's packed RCCL combine (default) or the zero-fill + torch reduce fallback")
@@ -249,7 +297,7 @@ def main():
         if multi and not packed:
             frame.zero_()
         bc = ctx.render(scene, WIDTH, HEIGHT, DEPTH, seeds, rank=rank, world=world, band_rows=BAND_ROWS,
-                        d_image=frame.data_ptr(), stream=stream, count_bounces=count, async_=True)
+                        d_image=frame.data_ptr(), stream=stream, count_bounces=count, async_=True, fast_math=True)
         if multi:
             w = combine(frame)
             if w is not None:
@@ -283,7 +331,7 @@ def main():
             buf.zero_()
         # record_timing: the C ABI brackets the kernel with HIP events on the launch stream, no host sync
         ctx.render(scene, WIDTH, HEIGHT, DEPTH, seeds, rank=rank, world=world, band_rows=BAND_ROWS,
-                   d_image=buf.data_ptr(), stream=stream, async_=True, record_timing=True)
+                   d_image=buf.data_ptr(), stream=stream, async_=True, record_timing=True, fast_math=True)
         if multi:
             pending[k % 2] = combine(buf)
     for w in pending:
@@ -298,23 +346,25 @@ def main():
     assert len(kern_times) == args.steps, (len(kern_times), args.steps)
     kern_ms = float(np.mean(kern_times))
 
-    # outside the timed region: rows of the frame the last timed step left (rank 0 holds the whole image, after the
-    # reduce when N > 1) against the CPU oracle at the full sample count, bit for bit
-    verified = 0
+    # outside the timed region: the frame the last timed step left (rank 0 holds the whole image, after the combine when
+    # N > 1) against the reference kernel's own frame, every pixel, bit for bit
+    verified = None
     if rank == 0 and not args.no_verify:
         torch.cuda.synchronize()
-        rows = [frame[r].cpu().numpy() for r in VERIFY_ROWS]
-        verified = verify_frame(rows, scene, seeds, VERIFY_ROWS)
+        verified = verify_against_reference_kernel(frame.cpu().numpy(), scene, seeds, WIDTH, HEIGHT, DEPTH)
 
-    # untimed extra (rank-local, N=1 only): the opt-in relaxed-float build of the same kernel, for the roofline
-    # discussion — NOT the reported value, its image is within tolerance of the oracle, not bit-identical
-    fast_ms = None
-    if world == 1 and not args.no_fast_math:
+    # untimed extra (rank-local, N=1 only): the strict-IEEE build of the same kernel (bit-identical to the CPU oracle:
+    # six rows of its frame are checked against it at the full sample count)
+    strict_ms, strict_rows = None, 0
+    if world == 1 and not multi and not args.no_strict:
         for _ in range(1 + min(args.steps, 3)):
             ctx.render(scene, WIDTH, HEIGHT, DEPTH, seeds, d_image=frame.data_ptr(), stream=stream, async_=True,
-                       record_timing=True, fast_math=True)
+                       record_timing=True, fast_math=False)
         torch.cuda.synchronize()
-        fast_ms = float(np.mean(ctx.kernel_times()[1:]))
+        strict_ms = float(np.mean(ctx.kernel_times()[1:]))
+        if not args.no_verify:
+            rows = [frame[r].cpu().numpy() for r in VERIFY_ROWS]
+            strict_rows = verify_frame(rows, scene, seeds, VERIFY_ROWS)
     tb = torch.tensor([float(my_bounces), dt, kern_ms], dtype=torch.float64, device=dev)
     if multi:
         tsum = tb.clone()
@@ -352,9 +402,10 @@ def main():
                                    % (16.0 * WIDTH * HEIGHT * (world - 1) / world / 1e6, world - 1)) if packed else
                                   "fallback: zero-filled full frames + torch.distributed reduce(sum), %.1f MB per rank per step" % (16.0 * WIDTH * HEIGHT / 1e6),
                        "bounces_per_sample": round(bps, 3),
-                       "verified_rows": verified,
-                       "verified": ("rows %s of the last timed frame bit-identical to the CPU oracle at %d spp" % (list(VERIFY_ROWS), spp))
-                                   if verified else "skipped"},
+                       "arithmetic": "the reference kernel's own: its float operations as its OpenCL build for gfx950 performs them "
+                                     "(pt_render_args.fast_math = 1, the default of the renderer.h drop-in; DESIGN.md section 2)",
+                       "verified_pixels": WIDTH * HEIGHT if verified else 0,
+                       "verified": verified or ("skipped" if args.no_verify else "reference code object not in the tree: not checked in this run")},
             "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_VALU_TFLOPS,
                          # HBM bytes per launch: the counter reading of the newest PMC summary of this kernel in profiles/
@@ -362,18 +413,19 @@ def main():
                          # bytes (16 B/pixel written once + the tables and seeds read) are given beside it
                          "traffic": traffic, "traffic_source": traffic_file,
                          "traffic_model": 16.0 * WIDTH * HEIGHT / max(world, 1) + 432 + 8 * spp,
-                         "kernel": "pt_render_lds_kernel", "kernel_ms": kern_ms,
+                         "kernel": "pt_fast::pt_render_lds_kernel", "kernel_ms": kern_ms,
                          "flops_per_sample": round(fps, 1),
                          "note": "FP32 vector roofline (no dense contraction on this path, SURVEY.md §8d); "
                                  "algorithmic FLOPs = B*(18N+34+30)+60 per sample with B measured in-kernel"},
         }
-        if fast_ms is not None:
-            out["fast_math"] = {"value": samples / (fast_ms * 1e-3) / 1e6, "unit": "Msamples/s", "kernel_ms": fast_ms,
-                                "frac": fps * samples / (fast_ms * 1e-3) / 1e12 / PEAK_FP32_VALU_TFLOPS,
-                                "note": "opt-in build of the same kernel (pt_render_args.fast_math / PT_MATH=fast): FMA contraction, "
-                                        "1-ulp v_sqrt_f32/v_rcp_f32, as the reference's own -cl-fast-relaxed-math allows; same RNG "
-                                        "stream, image within the tolerance of tests/test_gpu_fast_math.py, not bit-identical; "
-                                        "kernel time only, not the reported value"}
+        if strict_ms is not None:
+            out["strict_build"] = {"value": samples / (strict_ms * 1e-3) / 1e6, "unit": "Msamples/s", "kernel_ms": strict_ms,
+                                   "frac": fps * samples / (strict_ms * 1e-3) / 1e12 / PEAK_FP32_VALU_TFLOPS,
+                                   "verified_rows": strict_rows,
+                                   "note": "the strict-IEEE build of the same kernel (pt_render_args.fast_math = 0 / PT_MATH=strict): IEEE binary32 "
+                                           "in the reference's source order, no contraction, correctly rounded sqrt and divide; bit-identical to "
+                                           "the CPU oracle (rows %s of its frame checked at %d spp), within the stated tolerance of the reference "
+                                           "kernel's frame; kernel time only, not the reported value" % (list(VERIFY_ROWS), spp)}
         if world == 1 and not multi and not args.no_extras and spp == SPP:
             out["extras"] = extras(ctx, stream, torch, hip, scenes, seedmod)
         if world == 1 and not args.no_cpu_baseline:

@@ -283,6 +283,11 @@ static void fill_render_args(pt_render_args *a, const Renderer *renderer) {
 	a->cam_rot[0] = renderer->camera.rot.x; a->cam_rot[1] = renderer->camera.rot.y; a->cam_rot[2] = renderer->camera.rot.z;
 	a->sensor_width = renderer->camera.sensorWidth; a->focal_length = renderer->camera.focalLength;
 	a->aperture = renderer->camera.aperture; a->exposure = renderer->camera.exposure;
+	/* The drop-in renders with the reference's own arithmetic: the float operations of its kernel as its OpenCL build for
+	 * this GPU performs them (-cl-fast-relaxed-math, src/c/renderer.c:13; pt_hip.h `fast_math`), so that the image is the
+	 * one the reference produces on this device, bit for bit.  PT_MATH=strict selects the IEEE build (bit-identical to
+	 * the CPU oracle) instead. */
+	a->fast_math = 1;
 }
 
 static Image *render_failed(Renderer *renderer, const char *what) {

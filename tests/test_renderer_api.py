@@ -79,29 +79,58 @@ def test_struct_layouts_match_the_reference():
     assert [int(x) for x in out] == [16, 32, 48, 80, 48, 16, 32, 36, 40, 16, 16, 32, 16, 32]
 
 
+def expected_u8(oracle, math, sc, W, H, depth, seeds):
+    """The 8-bit image the drop-in must write.  math "strict" (PT_MATH=strict): the CPU oracle's.  math "reference" (the
+    default of renderer.c): the REFERENCE KERNEL's own accumulator on this GPU (tests/gpuref.py) through the reference's
+    host post-process (src/c/renderer.c:50-56,17-39, restated in the oracle library)."""
+    if math == "strict":
+        return oracle.postprocess(oracle.render(sc, W, H, depth, seeds)).reshape(H, W, 3)
+    import gpuref
+    k = gpuref.ReferenceKernel()
+    try:
+        img = k.render(sc, W, H, depth, seeds).copy()
+    finally:
+        k.close()
+    img[..., 3] = 0
+    return oracle.postprocess(img).reshape(H, W, 3)
+
+
+def math_env(math):
+    import gpuref
+    if math == "reference" and not gpuref.available():
+        pytest.skip("oracle/_ref/ptref_gfx950.hsaco not built (needs /root/reference at build time)")
+    return {"PT_MATH": "strict"} if math == "strict" else {}
+
+
 @pytest.mark.gpu
+@pytest.mark.parametrize("math", ["reference", "strict"])
 @pytest.mark.parametrize("pipeline", [0, 1])
-def test_scene_driver_frames_match_oracle(tmp_path, oracle, pipeline):
-    """Animation frames through create_renderer/…/render_to_file in a fresh process: the PNGs must hold
-    exactly the oracle's 8-bit image; every frame continues the rand() seed stream.  pipeline=1: the
-    frames are queued to the worker thread (PT_PIPELINE) — same files."""
+def test_scene_driver_frames_match_oracle(tmp_path, oracle, pipeline, math):
+    """Animation frames through create_renderer/…/render_to_file in a fresh process: the PNGs must hold exactly the 8-bit
+    image of the reference kernel on this GPU (the default arithmetic of the drop-in) or, with PT_MATH=strict, of the CPU
+    oracle; every frame continues the rand() seed stream.  pipeline=1: the frames are queued to the worker thread
+    (PT_PIPELINE) — same files."""
     W, H, spp = 96, 54, 8
     frames = (3, 4, 5, 6, 7) if pipeline else (3, 4)
     env = dict(os.environ, PT_NUM_GPUS="1", PT_PIPELINE=str(pipeline))
+    env.pop("PT_MATH", None)
+    env.update(math_env(math))
     pat = str(tmp_path / "frame%d.png")
     subprocess.check_call([os.path.join(PKG, "pt_scene_driver"), "3", str(len(frames)), str(W), str(H), str(spp), "50", pat],
                           env=env, cwd=str(tmp_path), timeout=100)
     stream = seedmod.glibc_rand_stream(len(frames) * spp)
     for k, i in enumerate(frames):
         sc = scenes.main_lua_frame(i)
-        want = oracle.postprocess(oracle.render(sc, W, H, 50, stream[k * spp:(k + 1) * spp])).reshape(H, W, 3)
+        want = expected_u8(oracle, math, sc, W, H, 50, stream[k * spp:(k + 1) * spp])
         got = read_png_rgb8(pat % i)
         assert np.array_equal(got, want), "frame %d: %d bytes differ" % (i, int((got != want).sum()))
         assert got.max() > 200
 
 
 def _driver_frames(tmp_path, env_extra, frames, W=96, H=54, spp=8):
-    env = dict(os.environ, PT_PIPELINE="0", **env_extra)
+    env = dict(os.environ, PT_PIPELINE="0")
+    env.pop("PT_MATH", None)
+    env.update(env_extra)
     pat = str(tmp_path / "frame%d.png")
     subprocess.check_call([os.path.join(PKG, "pt_scene_driver"), str(frames[0]), str(len(frames)), str(W), str(H), str(spp), "50", pat],
                           env=env, cwd=str(tmp_path), timeout=200)
@@ -109,16 +138,17 @@ def _driver_frames(tmp_path, env_extra, frames, W=96, H=54, spp=8):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("math", ["reference", "strict"])
 @pytest.mark.parametrize("ranks", [2, 3, 8])
-def test_band_ranks_on_one_gpu_merge_to_the_oracle_image(tmp_path, oracle, ranks):
+def test_band_ranks_on_one_gpu_merge_to_the_oracle_image(tmp_path, oracle, ranks, math):
     """renderer.c's multi-rank path end to end on ONE GPU (PT_SHARE_GPU=1: PT_NUM_GPUS contexts on GPU 0): per-rank band
     launches with global ids, pt_combine_bands' merge into rank 0's accumulator (device copies here, RCCL transfers
     between distinct GPUs), one conversion, one read-back.  The PNGs must hold the oracle's 8-bit image."""
     W, H, spp, frames = 96, 54, 8, (3, 4)
-    got = _driver_frames(tmp_path, {"PT_NUM_GPUS": str(ranks), "PT_SHARE_GPU": "1"}, frames)
+    got = _driver_frames(tmp_path, dict({"PT_NUM_GPUS": str(ranks), "PT_SHARE_GPU": "1"}, **math_env(math)), frames)
     stream = seedmod.glibc_rand_stream(len(frames) * spp)
     for k, i in enumerate(frames):
-        want = oracle.postprocess(oracle.render(scenes.main_lua_frame(i), W, H, 50, stream[k * spp:(k + 1) * spp])).reshape(H, W, 3)
+        want = expected_u8(oracle, math, scenes.main_lua_frame(i), W, H, 50, stream[k * spp:(k + 1) * spp])
         assert np.array_equal(got[k], want), "ranks %d frame %d: %d bytes differ" % (ranks, i, int((got[k] != want).sum()))
 
 
@@ -130,7 +160,7 @@ def test_two_gpus_combine_over_rccl(tmp_path, oracle):
     if hip.device_count() < 2:
         pytest.skip("needs two GPUs")
     W, H, spp, frames = 96, 54, 8, (3, 4)
-    got = _driver_frames(tmp_path, {"PT_NUM_GPUS": "2"}, frames)
+    got = _driver_frames(tmp_path, {"PT_NUM_GPUS": "2", "PT_MATH": "strict"}, frames)
     stream = seedmod.glibc_rand_stream(len(frames) * spp)
     for k, i in enumerate(frames):
         want = oracle.postprocess(oracle.render(scenes.main_lua_frame(i), W, H, 50, stream[k * spp:(k + 1) * spp])).reshape(H, W, 3)
@@ -190,8 +220,9 @@ def test_bench_rccl_path_executes_with_one_rank(tmp_path):
     """bench.py's N > 1 code path (process group, zero-fill, RCCL reduce, barrier, frame check) with a single rank."""
     import sys
     out = subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--force-dist", "--steps", "2", "--warmup", "1",
-                                   "--spp", "4", "--no-cpu-baseline", "--no-fast-math"], cwd=str(tmp_path), timeout=300,
+                                   "--spp", "4", "--no-cpu-baseline", "--no-strict"], cwd=str(tmp_path), timeout=300,
                                   env=dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29617"))
     import json
     line = json.loads(out.decode().strip().splitlines()[-1])
-    assert line["n_gpus"] == 1 and line["config"]["verified_rows"] == 6 and line["value"] > 0
+    assert line["n_gpus"] == 1 and line["value"] > 0
+    assert line["config"]["verified_pixels"] in (0, 1920 * 1080)      # 0: the reference code object is not in the tree
