@@ -60,8 +60,10 @@ PT_DEV float ocl_length_edge(float x, float y, float z, float l2) {
 }
 PT_DEV float ocl_length(f3 v) {
 	const float l2 = ocl_sumsq(v.x, v.y, v.z);
-	if(__builtin_expect(ocl_plain(l2), 1)) return ocl_sqrt(l2);
-	return ocl_length_edge(v.x, v.y, v.z, l2);
+	float r = ocl_sqrt(l2);
+	// one wave-level test for the rare path (no exec-mask juggling around the common one)
+	if(__builtin_expect(__builtin_amdgcn_ballot_w64(!ocl_plain(l2)) != 0, 0)) { if(!ocl_plain(l2)) r = ocl_length_edge(v.x, v.y, v.z, l2); }
+	return r;
 }
 // AMD's normalize(float3): v * rsq(fused sum of squares); zero vectors returned as they are, operands re-scaled when
 // the sum under- or overflows (infinite components become +-1, the others 0, as the library does) — the rare path;
@@ -89,9 +91,8 @@ PT_DEV float ocl_normalize_edge(float &x, float &y, float &z) {
 }
 PT_DEV f3 ocl_normalize(f3 v) {
 	const float l2 = ocl_sumsq(v.x, v.y, v.z);
-	float r;
-	if(__builtin_expect(ocl_plain(l2), 1)) r = ocl_rsq(l2);
-	else r = ocl_normalize_edge(v.x, v.y, v.z);
+	float r = ocl_rsq(l2);
+	if(__builtin_expect(__builtin_amdgcn_ballot_w64(!ocl_plain(l2)) != 0, 0)) { if(!ocl_plain(l2)) r = ocl_normalize_edge(v.x, v.y, v.z); }
 	f3 o; o.x = v.x * r; o.y = v.y * r; o.z = v.z * r;
 	return o;
 }

@@ -138,14 +138,14 @@ PT_DEV bool shade_hit(Path &pt, float t, const float4 g, const float4 mA, const 
 		return false;
 	}
 	if(!front && type != 3) return false;
-	f3 dir;
-	f3 mask;
-	if(type == 1) {                                                                      // ray.cl:136-141
-		const f3 ruv = random_unit_vector(pt.rng);
-		dir = add3(normal, ruv);
-		mask = mul3(mcol, pt.mask);
-	} else {
-		f3 base;
+	// The three scattering materials end in `direction = base + random_unit_vector * scale` with the same two RNG draws;
+	// ONE shared copy of the draw, so that a wave whose lanes hit different materials runs it once.  The reference's
+	// lambertian `normal + ruv` (a plain add) is fma(ruv, 1.0f, normal) bit for bit; the others are fused in its code
+	// object as written here.
+	const f3 mc = mul3(mcol, pt.mask);                                                   // color * mask, every material
+	f3 base = normal, mask = mc;                                                         // ray.cl:136-141
+	float scale = 1.0f;
+	if(type != 1) {
 		if(type == 2) base = reflection_dir(d, normal);                                  // ray.cl:145
 		else {                                                                           // ray.cl:150-171
 			const float cosTheta = fminf(1.0f, __builtin_fmaf(-d.z, normal.z, __builtin_fmaf(-d.y, normal.y, (-d.x) * normal.x)));
@@ -156,14 +156,13 @@ PT_DEV bool shade_hit(Path &pt, float t, const float4 g, const float4 mA, const 
 			if(!reflect) reflect = !(reflectance(cosTheta, schlick_r0(rel)) <= rand_float(pt.rng));      // short-circuit draw, ray.cl:163
 			base = reflect ? reflection_dir(d, normal) : refraction_dir(d, normal, rel, cosTheta);
 		}
-		const f3 ruv = random_unit_vector(pt.rng);
-		const float fuzz = mB.y;
-		dir = mk3(__builtin_fmaf(ruv.x, fuzz, base.x), __builtin_fmaf(ruv.y, fuzz, base.y), __builtin_fmaf(ruv.z, fuzz, base.z));
+		scale = mB.y;                                                                    // fuzzyness
 		// mask * (1 - tint) + mask * color * tint as compiled: fma(mask, 1 - tint, (color * mask) * tint)
 		const float tint = mB.x, omt = 1.0f - tint;
-		const f3 mc = mul3(mcol, pt.mask);
 		mask = mk3(__builtin_fmaf(pt.mask.x, omt, mc.x * tint), __builtin_fmaf(pt.mask.y, omt, mc.y * tint), __builtin_fmaf(pt.mask.z, omt, mc.z * tint));
 	}
+	const f3 ruv = random_unit_vector(pt.rng);
+	const f3 dir = mk3(__builtin_fmaf(ruv.x, scale, base.x), __builtin_fmaf(ruv.y, scale, base.y), __builtin_fmaf(ruv.z, scale, base.z));
 	pt.d = dir;
 	pt.o = offPos;
 	pt.mask = mask;
@@ -222,6 +221,7 @@ PT_DEV bool shade_hit(Path &pt, float t, const float4 g, const float4 mA, const 
 // ---------------------------------------------------------------------------------------
 struct Hit { bool hit; float t; int idx; };
 
+#if !PT_FAST_MATH
 // The reference scan, as written: sqrt and divide per candidate, strict `<` on the rounded distances.
 template <typename Tab>
 PT_DEV Hit closest_hit_reference(const Tab geom, int n, f3 o, f3 d, float a) {
@@ -236,9 +236,11 @@ PT_DEV Hit closest_hit_reference(const Tab geom, int n, f3 o, f3 d, float a) {
 			const float t = (-bHalf - sqrtf(disc)) / a;
 			if(t > 0.0f && (!h.hit || t < h.t)) { h.hit = true; h.t = t; h.idx = i; }
 		}
+
 	}
 	return h;
 }
+#endif
 
 // Branch-free scan with ONE divide per ray instead of one per candidate.  Same result as
 // closest_hit_reference for every input; the argument:
@@ -259,6 +261,7 @@ PT_DEV Hit closest_hit_reference(const Tab geom, int n, f3 o, f3 d, float a) {
 //    are more than an ulp apart.  Otherwise: `slow`.
 //  `slow` lanes re-run the reference scan (whole wave skips it when no lane asks).
 constexpr uint32_t KEY_NONE = 0x7f800000u;   // bits(+inf)
+constexpr uint32_t KEY_NONE_FAST = 0x7f800001u;   // relaxed build: keys are bits(t), +inf included among the hits
 
 // src/cl/ray.cl:72-76 — bHalf and the discriminant, in the reference's operation order
 PT_DEV void sphere_disc(const float4 g, f3 o, f3 d, float a, float &bHalf, float &disc) {
@@ -294,9 +297,12 @@ PT_DEV void candidate_key(float bHalf, float disc, int i, uint32_t &best, uint32
 #if PT_FAST_MATH
 	// relaxed build: the candidate's own distance, t = v_rcp_f32(a) * (-sqrt(disc) - b) as the reference's code object
 	// forms it, is the key — the strict `<` of ray.cl:104 on the very floats the reference compares, lowest index first.
-	// t > 0 (ray.cl:82) <=> bits(t) - 1 < bits(+inf); a negative disc gives a NaN t, which is no hit (ray.cl:78).
+	// A negative disc gives a NaN t, which is no hit (ray.cl:78).
 	const float tf = ra * (-__builtin_amdgcn_sqrtf(disc) - bHalf);
-	const uint32_t keyf = __float_as_uint(tf) - 1u;
+	// key = bits(t): every t > 0 up to +inf sorts below KEY_NONE_FAST, negative and NaN t above it.  t == +0 (no hit,
+	// ray.cl:82) sorts FIRST: it wins, finish_scan sees best == 0 and the lane re-runs the scan serially
+	// (closest_hit_serial / closest_hit_wave) — one compare per ray instead of one subtraction per candidate.
+	const uint32_t keyf = __float_as_uint(tf);
 	const bool updf = keyf < best;
 	idx = updf ? i : idx;
 	best = updf ? keyf : best;
@@ -321,6 +327,24 @@ PT_DEV void test_sphere(const float4 g, int i, f3 o, f3 d, float a, uint32_t &be
 	sphere_disc(g, o, d, a, bHalf, disc);
 	candidate_update(bHalf, disc, i, best, prev, idx, tiny, ra);
 }
+
+#if PT_FAST_MATH
+// The reference's loop as its code object runs it, one sphere after the other (ray.cl:101-110): the relaxed build's
+// fallback for the one case its key scan does not decide (a distance of exactly +0, see candidate_key).
+template <typename Tab>
+PT_DEV Hit closest_hit_serial(const Tab geom, int n, f3 o, f3 d, float a, float ra) {
+	Hit h; h.hit = false; h.t = 0.0f; h.idx = 0;
+	for(int i = 0; i < n; i++) {
+		float bHalf, disc;
+		sphere_disc(geom[i], o, d, a, bHalf, disc);
+		if(0.0f <= disc) {
+			const float t = ra * (-ocl_sqrt(disc) - bHalf);
+			if(t > 0.0f && (!h.hit || t < h.t)) { h.hit = true; h.t = t; h.idx = i; }
+		}
+	}
+	return h;
+}
+#endif
 
 // "This lane can hit the sphere" as a sign bit: disc >= 0 and bHalf < 0, i.e. sign(disc) clear and sign(bHalf) set, in
 // full-rate bit operations (the float form, min(disc, -bHalf) >= 0 over four spheres, is four v_min, three v_max and a
@@ -368,8 +392,9 @@ PT_DEV Hit finish_scan(float a, float rinv, uint32_t best, uint32_t prev, int id
 	h.hit = best < KEY_NONE;
 	h.idx = idx;
 #if PT_FAST_MATH
-	h.t = __uint_as_float(best + 1u);      // the key IS the winner's distance (candidate_key)
-	slow = false;
+	h.hit = best < KEY_NONE_FAST;
+	h.t = __uint_as_float(best);      // the key IS the winner's distance (candidate_key)
+	slow = best == 0u;                // a distance of +0 is no hit in the reference: the serial scan decides
 	return h;
 #endif
 	const float num = __uint_as_float(best);
@@ -383,13 +408,6 @@ PT_DEV Hit finish_scan(float a, float rinv, uint32_t best, uint32_t prev, int id
 	return h;
 }
 
-template <typename Tab>
-PT_DEV Hit finish_hit(const Tab geom, int n, f3 o, f3 d, float a, uint32_t best, uint32_t prev, int idx, float tiny) {
-	bool slow;
-	Hit h = finish_scan(a, __builtin_amdgcn_rcpf(a), best, prev, idx, tiny, slow);
-	if(__builtin_expect(slow, 0)) h = closest_hit_reference(geom, n, o, d, a);
-	return h;
-}
 
 // The reference scan for ONE ray by the whole wave: lane L tests spheres L, L+64, ... with the
 // reference's own arithmetic (sqrt and divide per sphere), then a lexicographic (t, index) minimum over
@@ -501,7 +519,11 @@ PT_DEV void scan_trio(uint32_t addr, bool skipBit, f3 o, f3 d, float a, float ra
 // run-time mask) or -2 (none).
 template <int NT, int MASK>
 PT_DEV Hit closest_hit_lds(uint32_t base, int n, unsigned long long skipMask, f3 o, f3 d, float a, float ya) {
+#if PT_FAST_MATH
+	uint32_t best = KEY_NONE_FAST, prev = KEY_NONE;
+#else
 	uint32_t best = KEY_NONE, prev = KEY_NONE;
+#endif
 	float tiny = scan_tiny_init(a);
 	int idx = 0;
 	uint32_t addr = base;
@@ -536,9 +558,13 @@ PT_DEV Hit closest_hit_lds(uint32_t base, int n, unsigned long long skipMask, f3
 	bool slow;
 	Hit h = finish_scan(a, ya * ya, best, prev, idx, tiny, slow);      // ya = v_rsq_f32(dot(d, d)): ya^2 seeds 1 / a (div_by_a)
 	if(__builtin_expect(slow, 0)) {
-		const float ln = len3(d);
 		const LdsGeom tab = {base};
+#if PT_FAST_MATH
+		h = closest_hit_serial(tab, n, o, d, a, ya);
+#else
+		const float ln = len3(d);
 		h = closest_hit_reference(tab, n, o, d, ln * ln);
+#endif
 		h.idx = (int)(base + lds_record_offset(h.idx));
 	}
 	return h;
@@ -868,7 +894,11 @@ __global__ __launch_bounds__(64) void pt_render_stream_kernel(float4 *__restrict
 			coop = 0;
 		} else if(__popcll(tmask) > PT_COOP_MAX_LANES) {
 			// ray-parallel: every lane scans the whole table for its own ray
+#if PT_FAST_MATH
+			uint32_t best = KEY_NONE_FAST, prev = KEY_NONE;
+#else
 			uint32_t best = KEY_NONE, prev = KEY_NONE;
+#endif
 			float tiny = scan_tiny_init(a);
 			int idx = 0;
 			if(nchunks > 1) {      // a table of one chunk was staged once, before the loop

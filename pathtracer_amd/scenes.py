@@ -195,6 +195,21 @@ def degenerate():
     return _pack(s, [0.4, 0.5, 0.7], cam)
 
 
+def on_surface():
+    """The camera sits EXACTLY on a sphere (|pos - centre|^2 == r^2 in binary32), looking into it: every primary ray meets
+    that sphere at distance exactly +0, which is no hit (`distance > 0`, src/cl/ray.cl:82) — the one value the kernels'
+    key scans cannot order and hand to their serial fallback.  A light and a mirror inside, a diffuse shell behind."""
+    s = [
+        _sphere(0, 0, -5, 5, lambertian(0.8, 0.3, 0.3)),               # the camera is on this one
+        _sphere(0.5, 0.25, -3, 1, light_source(4, 4, 3)),
+        _sphere(-1.5, -0.5, -4, 1, metal(0.9, 0.9, 0.9, 0.5, 0.0)),
+        _sphere(0, 0, -5, 8, lambertian(0.5, 0.6, 0.7)),               # concentric shell: seen from inside never (near root), from the gap yes
+        _sphere(0, 3, 2, 3, dielectric(0.9, 1.0, 0.9, 0.3, 0.0, 1.5)), # the camera is on this one too: 0 + 9 + 4 == 13 != 9 -> not exactly; plain neighbour
+    ]
+    cam = [0, 0, 0, 0.0, 0.0, 0.0, 6, 7, 0.02, 50]
+    return _pack(s, [0.4, 0.5, 0.7], cam)
+
+
 def empty():
     """No spheres: every path misses on its first bounce and returns the background."""
     cam = [0, 0, 0, 0, 0, 0, 15, 20, 0.001, 1000]

@@ -11,6 +11,7 @@ CASES = {
     "dense500_96x54": (lambda: scenes.dense_random(500), 96, 54, 50, 4),    # config 3 generator, small
     "dense3000_64x36": (lambda: scenes.dense_random(3000), 64, 36, 50, 2),
     "degenerate_64x48": (scenes.degenerate, 64, 48, 50, 8),                 # ties, duplicates, tangent / concentric spheres
+    "on_surface_48x36": (scenes.on_surface, 48, 36, 50, 4),                 # a hit distance of exactly +0 on every primary ray
     "dense12_48x27": (lambda: scenes.dense_random(12, seed=5), 48, 27, 50, 4),     # largest open-scene table on the lock-step kernel (PT_LOCKSTEP_MAX_SPHERES)
     "dense13_48x27": (lambda: scenes.dense_random(13, seed=5), 48, 27, 50, 4),     # first size on the streaming kernel
     "dense16_48x27": (lambda: scenes.dense_random(16, seed=3), 48, 27, 50, 4),     # five trios + one record; a quarter chunk of the streaming scan
