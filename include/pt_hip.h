@@ -67,11 +67,16 @@ typedef struct pt_render_args {
 	int record_timing;        /* 1: bracket the render kernel with a pair of HIP events on the launch stream
 	                             WITHOUT synchronising; collect the durations later with pt_kernel_times().
 	                             At most 256 launches between two collections.  Ignored when kernel_ms is set. */
-	int fast_math;            /* 0 (default): strict IEEE arithmetic in the reference's operation order — the image
-	                             is bit-identical to the CPU oracle.  1: the freedoms of the reference's own build
-	                             options (-cl-mad-enable -cl-fast-relaxed-math, src/c/renderer.c:13): FMA
-	                             contraction, 1-ulp hardware sqrt and reciprocal; same RNG stream, image within
-	                             tolerance.  The environment variable PT_MATH=fast|strict overrides this field. */
+	int fast_math;            /* Which arithmetic.  1: THE REFERENCE'S OWN — the float operations of its kernel as its OpenCL
+	                             build for this GPU performs them (the reference builds with -cl-mad-enable
+	                             -cl-fast-relaxed-math, src/c/renderer.c:13; ROCm's compiler then fuses products into
+	                             sums, uses v_rcp_f32 / v_sqrt_f32 / v_rsq_f32 bare and AMD's length / normalize / sin /
+	                             cos; every such choice is written out in pathtracer_amd/csrc/pt_device.h): the image
+	                             equals the reference kernel's output on MI355X BIT FOR BIT.  This is what the renderer.h
+	                             drop-in passes.  0: strict IEEE binary32 in the reference's SOURCE order, no fusion,
+	                             correctly rounded sqrt and divide — bit-identical to the CPU oracle, within the stated
+	                             tolerance of the reference kernel's image.  Same integer RNG stream either way.  The
+	                             environment variable PT_MATH=fast|strict (read by pt_ctx_create) overrides this field. */
 	int accel;                /* 0 (default): the reference's linear scan over all spheres (src/cl/ray.cl:101-110).
 	                             1: opt-in extension with no reference counterpart — the same closest hit (same
 	                             arithmetic per tested sphere, lowest index on equal distance) found through a
