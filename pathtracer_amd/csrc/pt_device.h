@@ -58,13 +58,16 @@ PT_DEV float ocl_length_edge(float x, float y, float z, float l2) {
 	}
 	return 0x1p-86f * ocl_sqrt_scaled(ocl_sumsq(0x1p86f * x, 0x1p86f * y, 0x1p86f * z));
 }
-PT_DEV float ocl_length(f3 v) {
+// `edge` is set where the rare path was taken (the caller's scan then runs serially: closest_hit_serial)
+PT_DEV float ocl_length(f3 v, bool &edge) {
 	const float l2 = ocl_sumsq(v.x, v.y, v.z);
 	float r = ocl_sqrt(l2);
+	edge = false;
 	// one wave-level test for the rare path (no exec-mask juggling around the common one)
-	if(__builtin_expect(__builtin_amdgcn_ballot_w64(!ocl_plain(l2)) != 0, 0)) { if(!ocl_plain(l2)) r = ocl_length_edge(v.x, v.y, v.z, l2); }
+	if(__builtin_expect(__builtin_amdgcn_ballot_w64(!ocl_plain(l2)) != 0, 0)) { if(!ocl_plain(l2)) { r = ocl_length_edge(v.x, v.y, v.z, l2); edge = true; } }
 	return r;
 }
+PT_DEV float ocl_length(f3 v) { bool e; return ocl_length(v, e); }
 // AMD's normalize(float3): v * rsq(fused sum of squares); zero vectors returned as they are, operands re-scaled when
 // the sum under- or overflows (infinite components become +-1, the others 0, as the library does) — the rare path;
 // returns the factor and may replace the components

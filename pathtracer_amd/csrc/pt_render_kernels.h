@@ -338,8 +338,11 @@ PT_DEV Hit closest_hit_serial(const Tab geom, int n, f3 o, f3 d, float a, float 
 		float bHalf, disc;
 		sphere_disc(geom[i], o, d, a, bHalf, disc);
 		if(0.0f <= disc) {
+			// the comparisons as the reference's finite-math-only code object makes them: a NaN distance passes both
+			// (`distance > 0` is !(0 >= t), `newDistance < distance` is !(t >= distance)), and a NaN `distance` is
+			// overwritten by whatever hit comes next
 			const float t = ra * (-ocl_sqrt(disc) - bHalf);
-			if(t > 0.0f && (!h.hit || t < h.t)) { h.hit = true; h.t = t; h.idx = i; }
+			if(!(0.0f >= t) && (!h.hit || !(t >= h.t))) { h.hit = true; h.t = t; h.idx = i; }
 		}
 	}
 	return h;
@@ -518,7 +521,7 @@ PT_DEV void scan_trio(uint32_t addr, bool skipBit, f3 o, f3 d, float a, float ra
 // reference's nine-sphere scene: 165.9 -> 162 ms).  NT == 0: any table; MASK < 0 is then -1 (small-sphere tests by the
 // run-time mask) or -2 (none).
 template <int NT, int MASK>
-PT_DEV Hit closest_hit_lds(uint32_t base, int n, unsigned long long skipMask, f3 o, f3 d, float a, float ya) {
+PT_DEV Hit closest_hit_lds(uint32_t base, int n, unsigned long long skipMask, f3 o, f3 d, float a, float ya, bool edge = false) {
 #if PT_FAST_MATH
 	uint32_t best = KEY_NONE_FAST, prev = KEY_NONE;
 #else
@@ -557,6 +560,9 @@ PT_DEV Hit closest_hit_lds(uint32_t base, int n, unsigned long long skipMask, f3
 	for(; i < n; i++, addr += PT_REC_BYTES) test_sphere(lds_f4(addr), (int)addr, o, d, a, best, prev, idx, tiny, ya);
 	bool slow;
 	Hit h = finish_scan(a, ya * ya, best, prev, idx, tiny, slow);      // ya = v_rsq_f32(dot(d, d)): ya^2 seeds 1 / a (div_by_a)
+#if PT_FAST_MATH
+	slow |= edge;      // |d|^2 outside the normal range: distances may be NaN, which only the serial scan orders as the reference does
+#endif
 	if(__builtin_expect(slow, 0)) {
 		const LdsGeom tab = {base};
 #if PT_FAST_MATH
@@ -645,14 +651,19 @@ __global__ PT_LDS_BOUNDS void pt_render_lds_kernel(float4 *__restrict__ image, c
 					if(COUNT) myBounces++;
 #if PT_FAST_MATH
 					// as compiled: length(d) = v_sqrt_f32 of the fused sum of squares, a = len * len, 1 / a = v_rcp_f32(a)
-					const float ln = ocl_length(pt.d);
+					bool edge;
+					const float ln = ocl_length(pt.d, edge);
 					const float a = ln * ln, ya = ocl_rcp(a);
 #else
 					float ya;
 					const float ln = sqrt_pos_y(dot3(pt.d, pt.d), ya);                   // see closest_hit_lds()
 					const float a = ln * ln;                                             // ray.cl:73 pow(length(d),2)
 #endif
+#if PT_FAST_MATH
+					const Hit h = closest_hit_lds<NT, MASK>(ldsBase, p.n, p.trioSkipMask, pt.o, pt.d, a, ya, edge);
+#else
 					const Hit h = closest_hit_lds<NT, MASK>(ldsBase, p.n, p.trioSkipMask, pt.o, pt.d, a, ya);
+#endif
 					if(!h.hit) { color = mul3(pt.mask, mk3(p.bgx, p.bgy, p.bgz)); break; }   // ray.cl:112-115
 					const uint32_t rec = (uint32_t)h.idx;
 					if(shade_hit(pt, h.t, lds_f4(rec), lds_f4(rec + 16), lds_f4(rec + 32), color)) break;
@@ -878,9 +889,14 @@ __global__ __launch_bounds__(64) void pt_render_stream_kernel(float4 *__restrict
 		// ---- one bounce of every lane that owns a pixel
 		const bool tracing = has && j < p.maxDepth;                                      // ray.cl:96
 		float a = 1.0f, rcpA = 1.0f;
+		bool edge = false;      // relaxed build: |d|^2 outside the normal range (see closest_hit_serial)
 		if(tracing) {
 			if(COUNT) myBounces++;
+#if PT_FAST_MATH
+			const float ln = ocl_length(pt.d, edge);
+#else
 			const float ln = len3(pt.d);
+#endif
 			a = ln * ln;                                                                 // ray.cl:73
 			rcpA = __builtin_amdgcn_rcpf(a);      // strict build: seed of finish_scan's divide; relaxed build: the reference's 1 / a
 		}
@@ -939,6 +955,10 @@ __global__ __launch_bounds__(64) void pt_render_stream_kernel(float4 *__restrict
 			const Hit hw = closest_hit_wave(sc.geom, p.n, ro, rd, ra, lane);
 			if(lane == L) h = hw;
 		}
+#if PT_FAST_MATH
+		// distances that may be NaN are ordered by the reference's own sequential rule only (whatever scan ran above)
+		if(__builtin_expect(__builtin_amdgcn_ballot_w64(tracing && edge) != 0, 0)) { if(tracing && edge) h = closest_hit_serial(sc.geom, p.n, pt.o, pt.d, a, rcpA); }
+#endif
 		bool ended = false;
 		f3 color = mk3(0.0f, 0.0f, 0.0f);                                                // ray.cl:92,174
 		if(tracing) {
