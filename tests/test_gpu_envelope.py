@@ -4,7 +4,7 @@ The reference pins no OpenCL runtime and builds with -cl-fast-relaxed-math (/roo
 its own float output is a family of images: tests/golden/env_*.npz hold the same scene through five x86 builds of the
 reference kernel (strict; its own flags with four legal definitions of sin/cos/sqrt/pow/dot/length/normalize).  Bar:
   * the strict HIP build IS one member (the strict build), bit for bit;
-  * the strict AND the relaxed (pt_fast) HIP builds are, against EVERY member, within the stated tolerance — share of
+  * the strict AND the relaxed (pt_fast: the reference's own gfx950 arithmetic, pinned bit for bit elsewhere) HIP builds are, against EVERY member, within the stated tolerance — share of
     pixels within 1e-4 on the linear image, PSNR of the 8-bit image (device epilogue vs the reference's host
     post-process), image mean — which is the tolerance the members meet among themselves
     (tests/test_oracle_golden.py::test_stated_tolerance_holds_over_the_envelope_of_legal_reference_builds)."""
