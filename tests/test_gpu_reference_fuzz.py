@@ -10,7 +10,7 @@ anywhere), rendered by the reference's own code object with its launch-per-sampl
     distance from the reference kernel's image is reported, and on reference-like scenes (diffuse or emissive walls, at
     most 3 specular / glass spheres) it stays within the stated flip budget (tests/envelope.py); image means agree.
 PT_REFFUZZ_CASES / PT_REFFUZZ_SEED: number of scenes and first seed (defaults 150 and 5000); PT_REFFUZZ_OUT: write the
-run's totals as JSON (a one-off run of 20 000 scenes is recorded in profiles/r03_gpuref_fuzz.json)."""
+run's totals as JSON (one-off runs of 20 000 and of 200 000 scenes are recorded in profiles/r03_gpuref_fuzz.json and r03_gpuref_fuzz_200k.json)."""
 import json
 import os
 
