@@ -713,7 +713,11 @@ static int launch_frames(pt_ctx *c, const pt_render_args *a, float4 *img, hipStr
 	p.rank = a->rank; p.world = a->world; p.bandRows = a->band_rows;
 	const long long lp = local_rows64(a->height, a->rank, a->world, a->band_rows) * a->width;
 	p.localPixels = (int)lp;
-	if(lp == 0) return PT_OK;
+	if(lp == 0) {      // this rank owns no band of the image: nothing to launch, the outputs still get their values
+		if(a->bounce_count) *a->bounce_count = 0;
+		if(a->kernel_ms) *a->kernel_ms = 0.0f;
+		return PT_OK;
+	}
 
 	// float rules: strict (bit-identical to the oracle) unless the caller, or PT_MATH=fast, asks for the relaxed build
 	const bool fast = c->sw.math == 1 || (c->sw.math == 0 && a->fast_math != 0);
@@ -812,6 +816,7 @@ extern "C" int pt_render(pt_ctx *c, const pt_render_args *a) {
 		hipError_t es = hipStreamSynchronize(st);   // pageable staging buffer: finish the copy before reusing it
 		free(c->hostSeedmul);
 		c->hostSeedmul = hs; c->nHostSeeds = a->n_frames;
+		if(e0 != hipSuccess || e1 != hipSuccess || ec != hipSuccess || es != hipSuccess) c->nHostSeeds = 0;      // the table's content is unknown: never skip the next upload
 		HIP_TRY(e0); HIP_TRY(e1); HIP_TRY(ec); HIP_TRY(es);
 	}
 
@@ -1215,8 +1220,9 @@ extern "C" int pt_selftest(pt_ctx *c, int op, const uint64_t *a, const uint64_t 
 	ST_TRY(hipMalloc((void **)&dou, nu));
 	ST_TRY(hipMalloc((void **)&dif, sizeof(float) * 2 * (size_t)n));
 	ST_TRY(hipMalloc((void **)&dof, sizeof(float) * 4 * (size_t)n));
-	ST_TRY(hipMemset(dou, 0, nu));
-	ST_TRY(hipMemset(dof, 0, sizeof(float) * 4 * (size_t)n));
+	// on the stream the kernel runs on (a non-blocking stream is not ordered after the null stream's work)
+	ST_TRY(hipMemsetAsync(dou, 0, nu, c->stream));
+	ST_TRY(hipMemsetAsync(dof, 0, sizeof(float) * 4 * (size_t)n, c->stream));
 	if(a) ST_TRY(hipMemcpy(da, a, nu, hipMemcpyHostToDevice));
 	if(b) ST_TRY(hipMemcpy(db, b, nu, hipMemcpyHostToDevice));
 	if(in_f) ST_TRY(hipMemcpy(dif, in_f, sizeof(float) * 2 * (size_t)n, hipMemcpyHostToDevice));

@@ -162,10 +162,10 @@ class Context:
         a.rank, a.world, a.band_rows = rank, world, band_rows
         a.d_image = d_image
         a.stream = stream
-        bc = C.c_uint64(0)
+        bc = C.c_uint64(0xdeadbeef)      # the library writes the count, also for a rank that owns no band
         a.bounce_count = C.pointer(bc) if count_bounces else None
         a.async_ = 1 if async_ else 0
-        ms = C.c_float(0)
+        ms = C.c_float(-1.0)
         a.kernel_ms = C.pointer(ms) if time_kernel else None
         a.record_timing = 1 if record_timing else 0
         a.fast_math = 1 if fast_math else 0

@@ -235,6 +235,12 @@ def test_frames_compose_and_partition(ctx, oracle):
     rows = (np.arange(54) // 16) % 2 == 1
     assert np.array_equal(bits(part[rows]), bits(full[rows]))
     assert not part[~rows].any()
+    # a rank that owns no band at all (one band, two ranks): nothing is written, and the outputs still get their values
+    ctx.image_alloc(96, 54)
+    assert ctx.render(sc, 96, 54, 50, s, rank=1, world=2, band_rows=100, count_bounces=True) == 0
+    assert ctx.render(sc, 96, 54, 50, s, rank=1, world=2, band_rows=100, time_kernel=True) == 0.0
+    assert ctx.render(sc, 96, 54, 50, s, rank=1, world=2, band_rows=100, noalloc=True, count_bounces=True) == 0
+    assert not ctx.image_read().any()
 
 
 def test_sample_interleaved_lanes_are_bit_identical(ctx, oracle):
