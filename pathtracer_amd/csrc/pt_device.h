@@ -49,6 +49,13 @@ PT_DEV float ocl_sqrt_scaled(float x) {
 }
 // FLT_MIN <= x < +inf in one unsigned compare (NaN, negative, zero, denormal and infinite x fail it)
 PT_DEV bool ocl_plain(float x) { return __float_as_uint(x) - 0x00800000u < 0x7f000000u; }
+// The wave's lanes whose x is NOT such a float, as a lane mask: ONE v_cmp_class_f32 on every class but "positive normal"
+// (the same set as !ocl_plain(x); written as asm because the compiler turns the class builtin back into add + compare)
+PT_DEV uint64_t ocl_odd_lanes(float x) {
+	uint64_t m;
+	asm("v_cmp_class_f32 %0, %1, %2" : "=s"(m) : "v"(x), "s"(0x2ffu));
+	return m;
+}
 // AMD's length(float3): sqrt of the fused sum of squares; operands re-scaled when that sum under- or overflows
 // (the rare path: ocl_length_edge)
 PT_DEV float ocl_length_edge(float x, float y, float z, float l2) {
@@ -64,7 +71,7 @@ PT_DEV float ocl_length(f3 v, bool &edge) {
 	float r = ocl_sqrt(l2);
 	edge = false;
 	// one wave-level test for the rare path (no exec-mask juggling around the common one)
-	if(__builtin_expect(__builtin_amdgcn_ballot_w64(!ocl_plain(l2)) != 0, 0)) { if(!ocl_plain(l2)) { r = ocl_length_edge(v.x, v.y, v.z, l2); edge = true; } }
+	if(__builtin_expect(ocl_odd_lanes(l2) != 0, 0)) { if(!ocl_plain(l2)) { r = ocl_length_edge(v.x, v.y, v.z, l2); edge = true; } }
 	return r;
 }
 PT_DEV float ocl_length(f3 v) { bool e; return ocl_length(v, e); }
@@ -95,7 +102,7 @@ PT_DEV float ocl_normalize_edge(float &x, float &y, float &z) {
 PT_DEV f3 ocl_normalize(f3 v) {
 	const float l2 = ocl_sumsq(v.x, v.y, v.z);
 	float r = ocl_rsq(l2);
-	if(__builtin_expect(__builtin_amdgcn_ballot_w64(!ocl_plain(l2)) != 0, 0)) { if(!ocl_plain(l2)) r = ocl_normalize_edge(v.x, v.y, v.z); }
+	if(__builtin_expect(ocl_odd_lanes(l2) != 0, 0)) { if(!ocl_plain(l2)) r = ocl_normalize_edge(v.x, v.y, v.z); }
 	f3 o; o.x = v.x * r; o.y = v.y * r; o.z = v.z * r;
 	return o;
 }
@@ -276,8 +283,10 @@ PT_DEV uint32_t init_rng_2(uint32_t id, uint64_t xb) {
 // The f64 divide is replaced by a multiply with RN(1/M): tests/test_rng_exhaustive.py checks on the
 // CPU, for every one of the 2^31 - 1 states, that the narrowed float is identical.
 PT_DEV float rand_float(uint32_t &state) {
-	uint64_t p = (uint64_t)state * 16807u;
-	uint32_t t = (uint32_t)(p & PT_M31) + (uint32_t)(p >> 31);
+	// p = 16807 * state, folded as (p mod 2^31) + (p >> 31).  Multiplying by 2 * 16807 instead puts p >> 31 in the high
+	// word of the product and (p mod 2^31) << 1 in the low word: one shift and one add instead of and, alignbit, add.
+	uint64_t p2 = (uint64_t)state * 33614u;
+	uint32_t t = ((uint32_t)p2 >> 1) + (uint32_t)(p2 >> 32);
 	uint32_t u = t - PT_M31;
 	state = u < t ? u : t;
 	return (float)((double)state * (1.0 / 2147483647.0));
