@@ -131,8 +131,12 @@ PT_DEV bool shade_hit(Path &pt, float t, const float4 g, const float4 mA, const 
 	f3 normal = ocl_normalize(sub3(hitPos, mk3(g.x, g.y, g.z)));                                                                // ray.cl:118
 	const f3 offPos = mk3(__builtin_fmaf(-0.0001f, normal.x, hitPos.x), __builtin_fmaf(-0.0001f, normal.y, hitPos.y),
 	                      __builtin_fmaf(-0.0001f, normal.z, hitPos.z));                                                        // ray.cl:119, fused, outward normal
+	// computed HERE (the empty asm pins it): the compiler otherwise sinks these three below the material branches, keeps the
+	// normal alive for them, and pays three register copies for the `base` that the branches overwrite
+	asm volatile("" :: "v"(offPos.x), "v"(offPos.y), "v"(offPos.z));
 	const bool front = 0.0f >= ocl_dot(d, normal);                                                                              // ray.cl:122 as !(dot > 0)
-	if(!front) normal = mk3(-normal.x, -normal.y, -normal.z);
+	// ray.cl:126 turns the normal of a back face round.  Only the dielectric goes on from a back face (below), so the three
+	// selects are made there and not for every hit.
 	if(type <= 0) {
 		if(front && type == 0) { color = mul3(mcol, pt.mask); return true; }
 		return false;
@@ -148,6 +152,7 @@ PT_DEV bool shade_hit(Path &pt, float t, const float4 g, const float4 mA, const 
 	if(type != 1) {
 		if(type == 2) base = reflection_dir(d, normal);                                  // ray.cl:145
 		else {                                                                           // ray.cl:150-171
+			if(!front) normal = mk3(-normal.x, -normal.y, -normal.z);                    // ray.cl:126
 			const float cosTheta = fminf(1.0f, __builtin_fmaf(-d.z, normal.z, __builtin_fmaf(-d.y, normal.y, (-d.x) * normal.x)));
 			const float rinv = ocl_rcp(mB.z);
 			const float sinTheta = ocl_sqrt(__builtin_fmaf(-cosTheta, cosTheta, 1.0f));
@@ -178,8 +183,9 @@ PT_DEV bool shade_hit(Path &pt, float t, const float4 g, const float4 mA, const 
 	const f3 hitPos = add3(pt.o, scl3(d, t));                                            // ray.cl:117
 	f3 normal = norm3(sub3(hitPos, mk3(g.x, g.y, g.z)));                                 // ray.cl:118
 	const f3 offPos = sub3(hitPos, scl3(normal, 0.0001f));                               // ray.cl:119 (outward normal)
-	bool front = true;
-	if(dot3(d, normal) > 0.0f) { front = false; normal = scl3(normal, -1.0f); }          // ray.cl:122-128
+	asm volatile("" :: "v"(offPos.x), "v"(offPos.y), "v"(offPos.z));                     // computed here, not below the branches (see the relaxed form above)
+	const bool front = !(dot3(d, normal) > 0.0f);                                        // ray.cl:122-128; the back face's normal is
+	                                                                                     // turned round where it is used: the dielectric
 	if(type <= 0) {                                                                      // ray.cl:130-134
 		if(front && type == 0) { color = mul3(pt.mask, mcol); return true; }
 		// back face of a light, or a material code none of ray.cl:130-171's branches matches (the table holds -1
@@ -198,6 +204,7 @@ PT_DEV bool shade_hit(Path &pt, float t, const float4 g, const float4 mA, const 
 		mask = add3(scl3(pt.mask, 1.0f - mB.x), scl3(mask, mB.x));                       // ray.cl:147,170
 		if(type == 2) base = reflection_dir(d, normal);                                  // ray.cl:145
 		else {                                                                           // ray.cl:150-171
+			if(!front) normal = scl3(normal, -1.0f);                                     // ray.cl:126
 			float rel = mB.z, r0 = mB.w;                                                 // mB.w: Schlick r0 of refIdx, folded on the host
 			if(!front) { rel = pt_div(1.0f, mB.z); r0 = schlick_r0(rel); }               // ray.cl:152
 			const float cosTheta = fminf(dot3(scl3(d, -1.0f), normal), 1.0f);
