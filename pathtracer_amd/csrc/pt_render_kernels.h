@@ -123,17 +123,22 @@ PT_DEV float mean_step(float acc, float c, float f, float f1, float r) {        
 
 #if PT_FAST_MATH
 // src/cl/ray.cl:117-171 as the reference's gfx950 code object computes it (see pt_device.h).  `g.w` is not used here.
+// LOCKSTEP: where the offset point is formed (same value either way; each kernel keeps the place that is faster for it:
+// headline frame 107.8 -> 106.6 ms with the later place, 10^4 spheres on the streaming kernel 148.8 -> 150.2 ms).
+template <bool LOCKSTEP>
 PT_DEV bool shade_hit(Path &pt, float t, const float4 g, const float4 mA, const float4 mB, f3 &color) {
 	const int type = __float_as_int(mA.w);
 	const f3 mcol = mk3(mA.x, mA.y, mA.z);
 	const f3 d = pt.d;
 	const f3 hitPos = mk3(__builtin_fmaf(d.x, t, pt.o.x), __builtin_fmaf(d.y, t, pt.o.y), __builtin_fmaf(d.z, t, pt.o.z));      // ray.cl:117, fused
 	f3 normal = ocl_normalize(sub3(hitPos, mk3(g.x, g.y, g.z)));                                                                // ray.cl:118
-	const f3 offPos = mk3(__builtin_fmaf(-0.0001f, normal.x, hitPos.x), __builtin_fmaf(-0.0001f, normal.y, hitPos.y),
-	                      __builtin_fmaf(-0.0001f, normal.z, hitPos.z));                                                        // ray.cl:119, fused, outward normal
-	// computed HERE (the empty asm pins it): the compiler otherwise sinks these three below the material branches, keeps the
-	// normal alive for them, and pays three register copies for the `base` that the branches overwrite
-	asm volatile("" :: "v"(offPos.x), "v"(offPos.y), "v"(offPos.z));
+	f3 offPos = hitPos;
+	if(!LOCKSTEP) {
+		// above the material branches, for every lane with a hit (the empty asm pins it there: see below)
+		offPos = mk3(__builtin_fmaf(-0.0001f, normal.x, hitPos.x), __builtin_fmaf(-0.0001f, normal.y, hitPos.y),
+		             __builtin_fmaf(-0.0001f, normal.z, hitPos.z));                                                                 // ray.cl:119, fused, outward normal
+		asm volatile("" :: "v"(offPos.x), "v"(offPos.y), "v"(offPos.z));
+	}
 	const bool front = 0.0f >= ocl_dot(d, normal);                                                                              // ray.cl:122 as !(dot > 0)
 	// ray.cl:126 turns the normal of a back face round.  Only the dielectric goes on from a back face (below), so the three
 	// selects are made there and not for every hit.
@@ -142,6 +147,16 @@ PT_DEV bool shade_hit(Path &pt, float t, const float4 g, const float4 mA, const 
 		return false;
 	}
 	if(!front && type != 3) return false;
+	// The offset point, for the lanes that go on only and straight into the registers the loop carries the origin in: it is
+	// formed HERE (the empty asm pins it: the compiler would sink it below the material branches, keep the normal alive for
+	// it and copy the normal for the `base` that the branches overwrite), and the hit point is kept alive past it (the asm
+	// reads it), so that the three FMAs are three-address and need no copy into the origin's registers afterwards.
+	if(LOCKSTEP) {
+		offPos = mk3(__builtin_fmaf(-0.0001f, normal.x, hitPos.x), __builtin_fmaf(-0.0001f, normal.y, hitPos.y),
+		             __builtin_fmaf(-0.0001f, normal.z, hitPos.z));                                                                 // ray.cl:119, fused, outward normal
+		asm volatile("" :: "v"(offPos.x), "v"(offPos.y), "v"(offPos.z), "v"(hitPos.x), "v"(hitPos.y), "v"(hitPos.z));
+		pt.o = offPos;
+	}
 	// The three scattering materials end in `direction = base + random_unit_vector * scale` with the same two RNG draws;
 	// ONE shared copy of the draw, so that a wave whose lanes hit different materials runs it once.  The reference's
 	// lambertian `normal + ruv` (a plain add) is fma(ruv, 1.0f, normal) bit for bit; the others are fused in its code
@@ -173,13 +188,14 @@ PT_DEV bool shade_hit(Path &pt, float t, const float4 g, const float4 mA, const 
 	// are three-address v_fma straight into those registers (three copies fewer per bounce: 108.1 -> 106.9 ms)
 	asm volatile("" :: "v"(base.x), "v"(base.y), "v"(base.z));
 	pt.d = dir;
-	pt.o = offPos;
+	if(!LOCKSTEP) pt.o = offPos;
 	pt.mask = mask;
 	return false;
 }
 #else
 // src/cl/ray.cl:117-171 — everything after the closest hit is known.  Returns true when the path
-// ends here (front face of a light), with its colour in `color`.
+// ends here (front face of a light), with its colour in `color`.  (LOCKSTEP: used by the relaxed form only.)
+template <bool LOCKSTEP>
 PT_DEV bool shade_hit(Path &pt, float t, const float4 g, const float4 mA, const float4 mB, f3 &color) {
 	const int type = __float_as_int(mA.w);
 	const f3 mcol = mk3(mA.x, mA.y, mA.z);
@@ -677,7 +693,7 @@ __global__ PT_LDS_BOUNDS void pt_render_lds_kernel(float4 *__restrict__ image, c
 #endif
 					if(!h.hit) { color = mul3(pt.mask, mk3(p.bgx, p.bgy, p.bgz)); break; }   // ray.cl:112-115
 					const uint32_t rec = (uint32_t)h.idx;
-					if(shade_hit(pt, h.t, lds_f4(rec), lds_f4(rec + 16), lds_f4(rec + 32), color)) break;
+					if(shade_hit<true>(pt, h.t, lds_f4(rec), lds_f4(rec + 16), lds_f4(rec + 32), color)) break;
 				}
 			}
 			if(S == 1) acc = accumulate(acc, color, p, p.firstFrame + k0);
@@ -974,7 +990,7 @@ __global__ __launch_bounds__(64) void pt_render_stream_kernel(float4 *__restrict
 		f3 color = mk3(0.0f, 0.0f, 0.0f);                                                // ray.cl:92,174
 		if(tracing) {
 			if(!h.hit) { color = mul3(pt.mask, mk3(p.bgx, p.bgy, p.bgz)); ended = true; }   // ray.cl:112-115
-			else ended = shade_hit(pt, h.t, sc.geom[h.idx], sc.matA[h.idx], sc.matB[h.idx], color);
+			else ended = shade_hit<false>(pt, h.t, sc.geom[h.idx], sc.matA[h.idx], sc.matB[h.idx], color);
 			j++;
 		}
 		if(has && !ended && j >= p.maxDepth) ended = true;                               // loop exhausted: black
