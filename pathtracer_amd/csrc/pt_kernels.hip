@@ -448,7 +448,10 @@ extern "C" int pt_scene_upload(pt_ctx *c, const float *spheres, int n) {
 		// the same four correctly rounded binary32 operations the kernel would repeat per hit
 		volatile float q = (1.0f - r[10]) / (1.0f + r[10]);
 		volatile float r0 = q * q;
-		hb[i] = make_float4(r[8], r[9], r[10], r0);
+		// .y is the factor of random_unit_vector() in the new direction (shade_hit): the fuzzyness for metal and
+		// dielectric (ray.cl:145,164,167), 1 for the lambertian, whose `normal + random_unit_vector` (ray.cl:138) is
+		// `normal + random_unit_vector * 1.0f` bit for bit and whose own fuzzyness field the reference never reads
+		hb[i] = make_float4(r[8], type == 1 ? 1.0f : r[9], r[10], r0);
 	}
 	// one stream, in order; the staging buffer is freed after the copies have completed
 	hipError_t e0 = hipMemcpyAsync(c->geomR, c->hostSpheres, sizeof(float4) * (size_t)n, hipMemcpyHostToDevice, c->stream);

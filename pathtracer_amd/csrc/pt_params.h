@@ -30,7 +30,8 @@ struct KParams {
 
 // Device scene tables (SoA).  geom[i] = {cx, cy, cz, r*r} for the strict build, {cx, cy, cz, r} for the relaxed one (the
 // reference's code object fuses r*r into r*r - |oc|^2); matA[i] = {colr, colg, colb, type bits};
-// matB[i] = {tint, fuzz, refIdx, ((1 - refIdx) / (1 + refIdx))^2}.
+// matB[i] = {tint, factor of random_unit_vector() in the new direction (fuzz; 1 for the lambertian), refIdx,
+// ((1 - refIdx) / (1 + refIdx))^2}.
 struct SceneTables {
 	const float4 *geom;
 	const float4 *matA;

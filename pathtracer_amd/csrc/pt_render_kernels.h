@@ -163,7 +163,7 @@ PT_DEV bool shade_hit(Path &pt, float t, const float4 g, const float4 mA, const 
 	// object as written here.
 	const f3 mc = mul3(mcol, pt.mask);                                                   // color * mask, every material
 	f3 base = normal, mask = mc;                                                         // ray.cl:136-141
-	float scale = 1.0f;
+	const float scale = mB.y;      // the table holds 1 for the lambertian, the fuzzyness for the others (pt_scene_upload)
 	if(type != 1) {
 		if(type == 2) base = reflection_dir(d, normal);                                  // ray.cl:145
 		else {                                                                           // ray.cl:150-171
@@ -176,7 +176,6 @@ PT_DEV bool shade_hit(Path &pt, float t, const float4 g, const float4 mA, const 
 			if(!reflect) reflect = !(reflectance(cosTheta, schlick_r0(rel)) <= rand_float(pt.rng));      // short-circuit draw, ray.cl:163
 			base = reflect ? reflection_dir(d, normal) : refraction_dir(d, normal, rel, cosTheta);
 		}
-		scale = mB.y;                                                                    // fuzzyness
 		// mask * (1 - tint) + mask * color * tint as compiled: fma(mask, 1 - tint, (color * mask) * tint)
 		const float tint = mB.x, omt = 1.0f - tint;
 		mask = mk3(__builtin_fmaf(pt.mask.x, omt, mc.x * tint), __builtin_fmaf(pt.mask.y, omt, mc.y * tint), __builtin_fmaf(pt.mask.z, omt, mc.z * tint));
@@ -218,9 +217,8 @@ PT_DEV bool shade_hit(Path &pt, float t, const float4 g, const float4 mA, const 
 	// branch: a wave whose lanes hit different materials runs it once (x * 1.0f is x, bit for bit, so the
 	// lambertian `normal + random_unit_vector` of ray.cl:138 is unchanged).
 	f3 base = normal, mask = mul3(pt.mask, mcol);                                        // ray.cl:138,140
-	float scale = 1.0f;
+	const float scale = mB.y;      // 1 for the lambertian, the fuzzyness for the others (pt_scene_upload), ray.cl:145,165,168
 	if(type != 1) {
-		scale = mB.y;                                                                    // fuzzyness, ray.cl:145,165,168
 		mask = add3(scl3(pt.mask, 1.0f - mB.x), scl3(mask, mB.x));                       // ray.cl:147,170
 		if(type == 2) base = reflection_dir(d, normal);                                  // ray.cl:145
 		else {                                                                           // ray.cl:150-171
