@@ -291,7 +291,7 @@ struct pt_ctx {
 	float4 *stage; size_t capStage;
 	void *mpComm; int mpWorld, mpRank;
 	float4 *image; int imgW, imgH;
-	float4 *geom, *geomR, *matA, *matB; int nSpheres, capSpheres;      // geomR: {centre, radius} for the relaxed build
+	float4 *geom, *geomR, *matA, *matB, *matC; int nSpheres, capSpheres;      // geomR: {centre, radius}, matC: derived dielectric constants, both for the relaxed build
 	uint64_t *seedmul; int capSeeds;
 	uint64_t *hostSeedmul; int nHostSeeds;   // what seedmul holds, to skip identical re-uploads
 	unsigned long long *counter;
@@ -370,7 +370,7 @@ extern "C" int pt_ctx_destroy(pt_ctx *c) {
 	if(!c) return PT_OK;
 	(void)hipSetDevice(c->device);
 	if(c->stream) (void)hipStreamSynchronize(c->stream);
-	(void)hipFree(c->image); (void)hipFree(c->geom); (void)hipFree(c->geomR); (void)hipFree(c->matA); (void)hipFree(c->matB);
+	(void)hipFree(c->image); (void)hipFree(c->geom); (void)hipFree(c->geomR); (void)hipFree(c->matA); (void)hipFree(c->matB); (void)hipFree(c->matC);
 	(void)hipFree(c->seedmul); (void)hipFree(c->counter); (void)hipFree(c->queue);
 	(void)hipFree(c->dCellStart); (void)hipFree(c->dItems); (void)hipFree(c->dBig);
 	free(c->hostSpheres); (void)hipFree(c->u8); (void)hipFree(c->stage);
@@ -400,12 +400,13 @@ extern "C" int pt_scene_upload(pt_ctx *c, const float *spheres, int n) {
 	if(!c || n < 0 || (n > 0 && !spheres)) return fail(PT_E_INVALID, "pt_scene_upload: bad arguments%s", NULL);
 	HIP_TRY(hipSetDevice(c->device));
 	if(n > c->capSpheres) {
-		(void)hipFree(c->geom); (void)hipFree(c->geomR); (void)hipFree(c->matA); (void)hipFree(c->matB);
-		c->geom = c->geomR = c->matA = c->matB = NULL; c->capSpheres = 0;
+		(void)hipFree(c->geom); (void)hipFree(c->geomR); (void)hipFree(c->matA); (void)hipFree(c->matB); (void)hipFree(c->matC);
+		c->geom = c->geomR = c->matA = c->matB = c->matC = NULL; c->capSpheres = 0;
 		HIP_TRY(hipMalloc((void **)&c->geom, sizeof(float4) * (size_t)n));
 		HIP_TRY(hipMalloc((void **)&c->geomR, sizeof(float4) * (size_t)n));
 		HIP_TRY(hipMalloc((void **)&c->matA, sizeof(float4) * (size_t)n));
 		HIP_TRY(hipMalloc((void **)&c->matB, sizeof(float4) * (size_t)n));
+		HIP_TRY(hipMalloc((void **)&c->matC, sizeof(float4) * (size_t)n));
 		c->capSpheres = n;
 	}
 	c->nSpheres = n;
@@ -458,9 +459,12 @@ extern "C" int pt_scene_upload(pt_ctx *c, const float *spheres, int n) {
 	hipError_t e1 = hipMemcpyAsync(c->geom, hg, sizeof(float4) * (size_t)n, hipMemcpyHostToDevice, c->stream);
 	hipError_t e2 = hipMemcpyAsync(c->matA, ha, sizeof(float4) * (size_t)n, hipMemcpyHostToDevice, c->stream);
 	hipError_t e3 = hipMemcpyAsync(c->matB, hb, sizeof(float4) * (size_t)n, hipMemcpyHostToDevice, c->stream);
+	// the relaxed build's derived table, from the table just uploaded, by that build's own instructions
+	pt_fast::derive_materials(c->matB, c->matC, n, c->stream);
+	hipError_t e5 = hipGetLastError();
 	hipError_t e4 = hipStreamSynchronize(c->stream);
 	free(h);
-	HIP_TRY(e0); HIP_TRY(e1); HIP_TRY(e2); HIP_TRY(e3); HIP_TRY(e4);
+	HIP_TRY(e0); HIP_TRY(e1); HIP_TRY(e2); HIP_TRY(e3); HIP_TRY(e5); HIP_TRY(e4);
 	return PT_OK;
 }
 
@@ -724,7 +728,7 @@ static int launch_frames(pt_ctx *c, const pt_render_args *a, float4 *img, hipStr
 
 	// float rules: strict (bit-identical to the oracle) unless the caller, or PT_MATH=fast, asks for the relaxed build
 	const bool fast = c->sw.math == 1 || (c->sw.math == 0 && a->fast_math != 0);
-	SceneTables sc = {fast ? c->geomR : c->geom, c->matA, c->matB};
+	SceneTables sc = {fast ? c->geomR : c->geom, c->matA, c->matB, c->matC};
 	LaunchPlan plan;
 	if(plan_launch(lp, a->first_frame, a->n_frames, c->sw, &plan) != PT_OK) return PT_E_INVALID;
 	p.logS = plan.logS; p.logS2 = plan.logS2;
@@ -757,7 +761,7 @@ static int launch_frames(pt_ctx *c, const pt_render_args *a, float4 *img, hipStr
 	if(c->sw.kernel == 2 && c->nSpheres <= PT_LDS_MAX_SPHERES) la.kernel = PT_K_LDS;
 	memset(&la.grid, 0, sizeof la.grid);
 	if(useGrid) { la.grid = c->grid; la.kernel = PT_K_GRID; }
-	la.ldsBytes = la.kernel == PT_K_LDS ? pt_strict::lds_table_bytes(c->nSpheres) : 0;
+	la.ldsBytes = la.kernel != PT_K_LDS ? 0 : fast ? pt_fast::lds_bytes(c->nSpheres) : pt_strict::lds_bytes(c->nSpheres);
 	la.genericScan = c->sw.genericScan;
 	// streaming kernel: persistent one-wave blocks, at most 32 per CU; surplus pixels come through the queue
 	const long long swaves = (lp + 63) / 64;

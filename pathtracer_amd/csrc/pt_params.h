@@ -31,11 +31,14 @@ struct KParams {
 // Device scene tables (SoA).  geom[i] = {cx, cy, cz, r*r} for the strict build, {cx, cy, cz, r} for the relaxed one (the
 // reference's code object fuses r*r into r*r - |oc|^2); matA[i] = {colr, colg, colb, type bits};
 // matB[i] = {tint, factor of random_unit_vector() in the new direction (fuzz; 1 for the lambertian), refIdx,
-// ((1 - refIdx) / (1 + refIdx))^2}.
+// ((1 - refIdx) / (1 + refIdx))^2}.  Relaxed build only: matC[i] = {1 / refIdx, Schlick r0 of refIdx, Schlick r0 of
+// 1 / refIdx, -}: what a dielectric hit used to compute per hit (two v_rcp_f32 and five more operations), derived ONCE per
+// scene by a kernel of that build (pt_fast::derive_materials), i.e. by the same instructions on the same GPU.
 struct SceneTables {
 	const float4 *geom;
 	const float4 *matA;
 	const float4 *matB;
+	const float4 *matC;
 };
 
 
@@ -73,5 +76,6 @@ struct LaunchArgs {
 };
 enum { PT_K_LDS = 0, PT_K_STREAM = 1, PT_K_GRID = 3 };
 
-namespace pt_strict { void launch_render(const LaunchArgs &la); }
-namespace pt_fast { void launch_render(const LaunchArgs &la); }
+// bytes of LDS the lock-step kernel of a build needs for a table of n spheres (the builds' records differ in size)
+namespace pt_strict { void launch_render(const LaunchArgs &la); size_t lds_bytes(int n); }
+namespace pt_fast { void launch_render(const LaunchArgs &la); size_t lds_bytes(int n); void derive_materials(const float4 *matB, float4 *matC, int n, hipStream_t stream); }

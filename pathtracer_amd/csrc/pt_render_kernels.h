@@ -125,8 +125,9 @@ PT_DEV float mean_step(float acc, float c, float f, float f1, float r) {        
 // src/cl/ray.cl:117-171 as the reference's gfx950 code object computes it (see pt_device.h).  `g.w` is not used here.
 // LOCKSTEP: where the offset point is formed (same value either way; each kernel keeps the place that is faster for it:
 // headline frame 107.8 -> 106.6 ms with the later place, 10^4 spheres on the streaming kernel 148.8 -> 150.2 ms).
-template <bool LOCKSTEP>
-PT_DEV bool shade_hit(Path &pt, float t, const float4 g, const float4 mA, const float4 mB, f3 &color) {
+// fetchC(): the sphere's matC row (pt_params.h), fetched only by a dielectric hit (LDS record + 48 / the global table).
+template <bool LOCKSTEP, typename FetchC>
+PT_DEV bool shade_hit(Path &pt, float t, const float4 g, const float4 mA, const float4 mB, f3 &color, FetchC fetchC) {
 	const int type = __float_as_int(mA.w);
 	const f3 mcol = mk3(mA.x, mA.y, mA.z);
 	const f3 d = pt.d;
@@ -169,11 +170,14 @@ PT_DEV bool shade_hit(Path &pt, float t, const float4 g, const float4 mA, const 
 		else {                                                                           // ray.cl:150-171
 			if(!front) normal = mk3(-normal.x, -normal.y, -normal.z);                    // ray.cl:126
 			const float cosTheta = fminf(1.0f, __builtin_fmaf(-d.z, normal.z, __builtin_fmaf(-d.y, normal.y, (-d.x) * normal.x)));
-			const float rinv = ocl_rcp(mB.z);
+			// 1 / refIdx = v_rcp_f32(refIdx) (ray.cl:156) and Schlick's r0 of the relative index (ray.cl:59-60) depend on the
+			// sphere and the face only: derived once per scene with these very instructions (derive_materials), read here
+			const float4 mC = fetchC();
 			const float sinTheta = ocl_sqrt(__builtin_fmaf(-cosTheta, cosTheta, 1.0f));
-			const float rel = front ? mB.z : rinv;
+			const float rel = front ? mB.z : mC.x;
+			const float r0 = front ? mC.y : mC.z;
 			bool reflect = 1.0f < sinTheta * rel;
-			if(!reflect) reflect = !(reflectance(cosTheta, schlick_r0(rel)) <= rand_float(pt.rng));      // short-circuit draw, ray.cl:163
+			if(!reflect) reflect = !(reflectance(cosTheta, r0) <= rand_float(pt.rng));      // short-circuit draw, ray.cl:163
 			base = reflect ? reflection_dir(d, normal) : refraction_dir(d, normal, rel, cosTheta);
 		}
 		// mask * (1 - tint) + mask * color * tint as compiled: fma(mask, 1 - tint, (color * mask) * tint)
@@ -194,8 +198,8 @@ PT_DEV bool shade_hit(Path &pt, float t, const float4 g, const float4 mA, const 
 #else
 // src/cl/ray.cl:117-171 — everything after the closest hit is known.  Returns true when the path
 // ends here (front face of a light), with its colour in `color`.  (LOCKSTEP: used by the relaxed form only.)
-template <bool LOCKSTEP>
-PT_DEV bool shade_hit(Path &pt, float t, const float4 g, const float4 mA, const float4 mB, f3 &color) {
+template <bool LOCKSTEP, typename FetchC>
+PT_DEV bool shade_hit(Path &pt, float t, const float4 g, const float4 mA, const float4 mB, f3 &color, FetchC) {
 	const int type = __float_as_int(mA.w);
 	const f3 mcol = mk3(mA.x, mA.y, mA.z);
 	const f3 d = pt.d;
@@ -475,8 +479,14 @@ PT_DEV Hit closest_hit_wave(const float4 *__restrict__ geom, int n, f3 o, f3 d, 
 // address, which arrives in a VGPR through the (otherwise idle) LDS pipe instead of a v_mov from the scalar loop
 // counter per sphere, and the shading reads geometry and materials at that address + 0/16/32 with no address
 // arithmetic.  The kernel is bound by the number of VALU instructions issued (profiles/r01_ubench_valu_issue_cost.md).
+#if PT_FAST_MATH
+// relaxed build: a fourth row per record, matC (pt_params.h), read only by a dielectric hit
+#define PT_REC_BYTES 64
+#define PT_TRIO_BYTES 208
+#else
 #define PT_REC_BYTES 48
 #define PT_TRIO_BYTES 160
+#endif
 typedef float pt_v4f __attribute__((ext_vector_type(4)));
 typedef int pt_v4i __attribute__((ext_vector_type(4)));
 // ds_read_b128 at a 32-bit LDS address (+ a constant offset the compiler folds into the instruction)
@@ -624,6 +634,9 @@ __global__ PT_LDS_BOUNDS void pt_render_lds_kernel(float4 *__restrict__ image, c
 		rec[0] = sc.geom[i];
 		rec[1] = sc.matA[i];
 		rec[2] = sc.matB[i];
+#if PT_FAST_MATH
+		rec[3] = sc.matC[i];
+#endif
 		if(i % 3 == 0 && i + 3 <= p.n) {
 			const int a0 = (int)(ldsBase + off);
 			*(int4 *)((char *)lds + off + 3 * PT_REC_BYTES) = make_int4(a0, a0 + PT_REC_BYTES, a0 + 2 * PT_REC_BYTES, 0);
@@ -691,7 +704,7 @@ __global__ PT_LDS_BOUNDS void pt_render_lds_kernel(float4 *__restrict__ image, c
 #endif
 					if(!h.hit) { color = mul3(pt.mask, mk3(p.bgx, p.bgy, p.bgz)); break; }   // ray.cl:112-115
 					const uint32_t rec = (uint32_t)h.idx;
-					if(shade_hit<true>(pt, h.t, lds_f4(rec), lds_f4(rec + 16), lds_f4(rec + 32), color)) break;
+					if(shade_hit<true>(pt, h.t, lds_f4(rec), lds_f4(rec + 16), lds_f4(rec + 32), color, [&]() { return lds_f4(rec + 48); })) break;
 				}
 			}
 			if(S == 1) acc = accumulate(acc, color, p, p.firstFrame + k0);
@@ -988,7 +1001,7 @@ __global__ __launch_bounds__(64) void pt_render_stream_kernel(float4 *__restrict
 		f3 color = mk3(0.0f, 0.0f, 0.0f);                                                // ray.cl:92,174
 		if(tracing) {
 			if(!h.hit) { color = mul3(pt.mask, mk3(p.bgx, p.bgy, p.bgz)); ended = true; }   // ray.cl:112-115
-			else ended = shade_hit<false>(pt, h.t, sc.geom[h.idx], sc.matA[h.idx], sc.matB[h.idx], color);
+			else ended = shade_hit<false>(pt, h.t, sc.geom[h.idx], sc.matA[h.idx], sc.matB[h.idx], color, [&]() { return sc.matC[h.idx]; });
 			j++;
 		}
 		if(has && !ended && j >= p.maxDepth) ended = true;                               // loop exhausted: black
@@ -1010,6 +1023,23 @@ __global__ __launch_bounds__(64) void pt_render_stream_kernel(float4 *__restrict
 	}
 }
 
+
+size_t lds_bytes(int n) { return lds_table_bytes(n); }
+
+#if PT_FAST_MATH
+// matC (pt_params.h): per sphere, what a dielectric hit needs beyond the reference's own fields, computed with the
+// instructions shade_hit() itself used per hit (v_rcp_f32 for 1 / refIdx, schlick_r0() for either face)
+__global__ __launch_bounds__(256) void pt_derive_materials_kernel(const float4 *__restrict__ matB, float4 *__restrict__ matC, int n) {
+	const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+	if(i >= n) return;
+	const float refIdx = matB[i].z;
+	const float rinv = ocl_rcp(refIdx);
+	matC[i] = make_float4(rinv, schlick_r0(refIdx), schlick_r0(rinv), 0.0f);
+}
+void derive_materials(const float4 *matB, float4 *matC, int n, hipStream_t stream) {
+	if(n > 0) hipLaunchKernelGGL(pt_derive_materials_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, matB, matC, n);
+}
+#endif
 
 // Launch one of the kernels of this build (error reporting: hipGetLastError() in the caller).
 void launch_render(const LaunchArgs &la) {

@@ -124,8 +124,10 @@ def test_noalloc_allocates_nothing_and_replays_from_a_graph(ctx, scene):
         gexec = C.c_void_p()
         assert lib.hipGraphInstantiate(C.byref(gexec), graph, None, None, 0) == 0
         for _ in range(2):
-            ctx.image_alloc(W, H)                               # zeroed: the replay must write every pixel itself
-            ctx.sync()
+            # another image in the accumulator first (one sample): the replay must write every pixel itself.  (Not a fresh
+            # pt_image_alloc: the graph holds the accumulator's address as it was at capture.)
+            ctx.render(sc, W, H, 50, s[:1], noalloc=True)
+            assert not np.array_equal(bits(ctx.image_read()), bits(want))
             assert lib.hipGraphLaunch(gexec, st) == 0
             assert lib.hipStreamSynchronize(st) == 0
             assert np.array_equal(bits(ctx.image_read()), bits(want))
