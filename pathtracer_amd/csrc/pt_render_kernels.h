@@ -126,8 +126,8 @@ PT_DEV float mean_step(float acc, float c, float f, float f1, float r) {        
 // LOCKSTEP: where the offset point is formed (same value either way; each kernel keeps the place that is faster for it:
 // headline frame 107.8 -> 106.6 ms with the later place, 10^4 spheres on the streaming kernel 148.8 -> 150.2 ms).
 // fetchC(): the sphere's matC row (pt_params.h), fetched only by a dielectric hit (LDS record + 48 / the global table).
-template <bool LOCKSTEP, typename FetchC>
-PT_DEV bool shade_hit(Path &pt, float t, const float4 g, const float4 mA, const float4 mB, f3 &color, FetchC fetchC) {
+template <bool LOCKSTEP, typename FetchC, typename StoreM>
+PT_DEV bool shade_hit(Path &pt, float t, const float4 g, const float4 mA, const float4 mB, f3 &color, FetchC fetchC, StoreM storeM) {
 	const int type = __float_as_int(mA.w);
 	const f3 mcol = mk3(mA.x, mA.y, mA.z);
 	const f3 d = pt.d;
@@ -192,14 +192,14 @@ PT_DEV bool shade_hit(Path &pt, float t, const float4 g, const float4 mA, const 
 	asm volatile("" :: "v"(base.x), "v"(base.y), "v"(base.z));
 	pt.d = dir;
 	if(!LOCKSTEP) pt.o = offPos;
-	pt.mask = mask;
+	storeM(mask);
 	return false;
 }
 #else
 // src/cl/ray.cl:117-171 — everything after the closest hit is known.  Returns true when the path
 // ends here (front face of a light), with its colour in `color`.  (LOCKSTEP: used by the relaxed form only.)
-template <bool LOCKSTEP, typename FetchC>
-PT_DEV bool shade_hit(Path &pt, float t, const float4 g, const float4 mA, const float4 mB, f3 &color, FetchC) {
+template <bool LOCKSTEP, typename FetchC, typename StoreM>
+PT_DEV bool shade_hit(Path &pt, float t, const float4 g, const float4 mA, const float4 mB, f3 &color, FetchC, StoreM storeM) {
 	const int type = __float_as_int(mA.w);
 	const f3 mcol = mk3(mA.x, mA.y, mA.z);
 	const f3 d = pt.d;
@@ -240,7 +240,7 @@ PT_DEV bool shade_hit(Path &pt, float t, const float4 g, const float4 mA, const 
 	}
 	pt.d = add3(base, scl3(random_unit_vector(pt.rng), scale));
 	pt.o = offPos;
-	pt.mask = mask;
+	storeM(mask);
 	return false;
 }
 #endif
@@ -668,6 +668,16 @@ __global__ PT_LDS_BOUNDS void pt_render_lds_kernel(float4 *__restrict__ image, c
 	// an IEEE divide per step; lanes 0..2 of the group hold the pixel's mean.  One launch-long switch per wave
 	// (`split`): it falls back to the plain form for good the first time a lane sees a value outside mean_safe().
 	__shared__ float4 meanSlot[2 * 256];
+	// The path's mask lives in LDS between bounce iterations (one private 16-byte slot per lane; volatile accesses, so
+	// that the compiler does not forward the store to the next iteration's load and rebuild the register value): as a
+	// loop-carried register value it cost six register copies per iteration around the divergent material branches (the
+	// structuriser's merge blocks carried it in registers of their own), while an LDS read and a write cost no vector
+	// instruction and the LDS pipe is a third busy: headline 104.9 -> 103.3 ms, the strict build 153.1 -> 149.8 ms.  It is
+	// read at the top of an iteration and written where a scattering hit forms the new one (shade_hit's storeM).
+	__shared__ float4 maskSlot[256];
+	const uint32_t maskAddr = (uint32_t)(uintptr_t)&maskSlot[threadIdx.x];
+#define PT_MASK_LOAD(m) do { const pt_v4f v_ = *(volatile __attribute__((address_space(3))) pt_v4f *)(uintptr_t)maskAddr; (m) = mk3(v_.x, v_.y, v_.z); } while(0)
+#define PT_MASK_STORE(m) do { pt_v4f v_; v_.x = (m).x; v_.y = (m).y; v_.z = (m).z; v_.w = 0.0f; *(volatile __attribute__((address_space(3))) pt_v4f *)(uintptr_t)maskAddr = v_; } while(0)
 	if(id >= 0) {
 		const f3 origin = camera_origin(p, id);
 		f3 acc = mk3(0.0f, 0.0f, 0.0f);
@@ -685,8 +695,10 @@ __global__ PT_LDS_BOUNDS void pt_render_lds_kernel(float4 *__restrict__ image, c
 			if(k < p.nFrames) {
 				Path pt;
 				start_sample(pt, p, id, origin, seedmul[k]);
+				PT_MASK_STORE(pt.mask);
 				for(int j = 0; j < p.maxDepth; j++) {                                    // ray.cl:96
 					if(COUNT) myBounces++;
+					PT_MASK_LOAD(pt.mask);
 #if PT_FAST_MATH
 					// as compiled: length(d) = v_sqrt_f32 of the fused sum of squares, a = len * len, 1 / a = v_rcp_f32(a)
 					bool edge;
@@ -704,7 +716,7 @@ __global__ PT_LDS_BOUNDS void pt_render_lds_kernel(float4 *__restrict__ image, c
 #endif
 					if(!h.hit) { color = mul3(pt.mask, mk3(p.bgx, p.bgy, p.bgz)); break; }   // ray.cl:112-115
 					const uint32_t rec = (uint32_t)h.idx;
-					if(shade_hit<true>(pt, h.t, lds_f4(rec), lds_f4(rec + 16), lds_f4(rec + 32), color, [&]() { return lds_f4(rec + 48); })) break;
+					if(shade_hit<true>(pt, h.t, lds_f4(rec), lds_f4(rec + 16), lds_f4(rec + 32), color, [&]() { return lds_f4(rec + 48); }, [&](f3 m) { PT_MASK_STORE(m); })) break;
 				}
 			}
 			if(S == 1) acc = accumulate(acc, color, p, p.firstFrame + k0);
@@ -1001,7 +1013,7 @@ __global__ __launch_bounds__(64) void pt_render_stream_kernel(float4 *__restrict
 		f3 color = mk3(0.0f, 0.0f, 0.0f);                                                // ray.cl:92,174
 		if(tracing) {
 			if(!h.hit) { color = mul3(pt.mask, mk3(p.bgx, p.bgy, p.bgz)); ended = true; }   // ray.cl:112-115
-			else ended = shade_hit<false>(pt, h.t, sc.geom[h.idx], sc.matA[h.idx], sc.matB[h.idx], color, [&]() { return sc.matC[h.idx]; });
+			else ended = shade_hit<false>(pt, h.t, sc.geom[h.idx], sc.matA[h.idx], sc.matB[h.idx], color, [&]() { return sc.matC[h.idx]; }, [&](f3 m) { pt.mask = m; });
 			j++;
 		}
 		if(has && !ended && j >= p.maxDepth) ended = true;                               // loop exhausted: black
